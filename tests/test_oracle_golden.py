@@ -1,0 +1,113 @@
+"""Pins the CPU oracle (`oracle/`) against vectors produced by the reference itself
+(`oracle/gen_golden.py`: HF SegGPT + `/root/reference/src/model.py` wrapper math)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from beach_seg_amd.weights import SegGptGeometry, synth_state_dict
+from oracle import predict_oracle as PO
+from oracle import seggpt_oracle as O
+from oracle.gen_inputs import synth_inputs
+
+
+def _e2e(g, rec, B):
+    w = synth_state_dict(g, seed=int(rec["wseed"]))
+    pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, int(rec["iseed"]))
+    assert np.array_equal(pal.numpy(), rec["palette"])
+    pn = O.palette_norm(pal)
+    np.testing.assert_allclose(pn.numpy(), rec["pal_norm"], rtol=0, atol=1e-6)
+    pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
+    lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
+    prm = prm.clone().requires_grad_(True)
+    pred = O.forward(w, g, pix, prm, pm, labels=lab)
+    loss = O.seggpt_loss(pred, lab, (lb_cls != 0)[:, None], 0.01, "reference")
+    (grad,) = torch.autograd.grad(loss, prm)
+    masks = O.decode_argmin(pred.detach(), pn)
+    return pred.detach(), float(loss), grad, masks, lab, lb_cls
+
+
+def test_tiny_end_to_end(golden_dir):
+    rec = np.load(golden_dir / "tiny_e2e.npz")
+    g = SegGptGeometry.tiny()
+    pred, loss, grad, masks, lab, lb_cls = _e2e(g, rec, 2)
+    np.testing.assert_allclose(pred.numpy(), rec["pred"], rtol=1e-4, atol=2e-5)
+    assert abs(loss - float(rec["loss"])) < 1e-5 * abs(float(rec["loss"]))
+    gref = rec["grad"]
+    assert np.abs(grad.numpy() - gref).max() < 1e-3 * np.abs(gref).max()
+    assert np.array_equal(masks.numpy().astype(np.uint8), rec["masks"])
+    for i in range(2):  # B=1 loss == per-sample masked mean (src/model.py:259 "Assume batch size 1")
+        l1 = O.seggpt_loss(pred[i:i + 1], lab[i:i + 1], (lb_cls != 0)[i:i + 1, None], 0.01, "per_sample")
+        assert abs(float(l1) - rec["loss_b1"][i]) < 1e-5
+
+
+def test_small_end_to_end(golden_dir):
+    rec = np.load(golden_dir / "small_e2e.npz")
+    g = SegGptGeometry.small()
+    pred, loss, grad, masks, _, _ = _e2e(g, rec, 2)
+    st = int(rec["stride"])
+    np.testing.assert_allclose(pred.numpy()[:, :, ::st, ::st], rec["pred_slice"], rtol=1e-4, atol=2e-5)
+    assert abs(loss - float(rec["loss"])) < 1e-5 * abs(float(rec["loss"]))
+    gs = rec["grad_slice"]
+    assert np.abs(grad.numpy()[:, :, ::st, ::st] - gs).max() < 1e-3 * np.abs(gs).max()
+    assert abs(float(pred.double().norm()) - float(rec["pred_l2"])) < 1e-4 * float(rec["pred_l2"])
+    assert abs(float(grad.double().norm()) - float(rec["grad_l2"])) < 1e-3 * float(rec["grad_l2"])
+    m8 = masks.numpy().astype(np.uint8)
+    assert np.array_equal(m8[:, ::st, ::st], rec["masks_slice"])
+    assert zlib.crc32(m8.tobytes()) == int(rec["masks_crc"])
+
+
+def test_feature_ensemble(golden_dir):
+    rec = np.load(golden_dir / "tiny_feature_ensemble.npz")
+    g = SegGptGeometry.tiny()
+    w = synth_state_dict(g, seed=int(rec["wseed"]))
+    pred = O.forward(w, g, torch.from_numpy(rec["pixel_values"]), torch.from_numpy(rec["prompt_pixel_values"]),
+                     torch.from_numpy(rec["prompt_masks"]), feature_ensemble=True)
+    np.testing.assert_allclose(pred.numpy(), rec["pred"], rtol=1e-4, atol=2e-5)
+
+
+def test_wrapper_math(golden_dir):
+    rec = np.load(golden_dir / "wrapper.npz")
+    assert np.array_equal(np.array(O.build_palette(3)), rec["build_palette_3"])
+    assert np.array_equal(np.array(O.build_palette(7)), rec["build_palette_7"])
+    pal = torch.from_numpy(rec["rand_palette_seed42"])
+    mask = torch.from_numpy(rec["mask"])
+    assert np.array_equal(O.apply_mask_rgb(pal, mask).numpy(), rec["apply_mask_rgb"])
+    pn = O.palette_norm(pal)
+    np.testing.assert_allclose(pn.numpy(), rec["pal_norm"], rtol=0, atol=1e-6)
+    pred = torch.from_numpy(rec["decode_pred"])
+    # decode from the reference's own normalised palette: must be bit-exact incl. the near-tie pixels
+    assert np.array_equal(O.decode_argmin(pred, torch.from_numpy(rec["pal_norm"])).numpy().astype(np.uint8),
+                          rec["decode_masks"])
+    labels = torch.from_numpy(rec["loss_labels"])
+    yes = mask != 0
+    for beta in (0.01, 0.5):
+        p = pred.clone().requires_grad_(True)
+        l3 = O.seggpt_loss(p, labels, yes, beta, "reference")
+        (g3,) = torch.autograd.grad(l3, p)
+        assert abs(float(l3) - float(rec[f"loss_B3_beta{beta}"])) < 1e-6 * abs(float(l3))
+        np.testing.assert_allclose(g3.numpy(), rec[f"loss_B3_grad_beta{beta}"], rtol=1e-5, atol=1e-9)
+        for i in range(3):
+            l1 = O.seggpt_loss(pred[i:i + 1], labels[i:i + 1], yes[i:i + 1], beta, "per_sample")
+            assert abs(float(l1) - rec[f"loss_B1_beta{beta}"][i]) < 1e-6
+
+
+def test_predict_glue(golden_dir):
+    rec = np.load(golden_dir / "predict_glue.npz")
+    counter = np.zeros((40, 50, 4), np.uint8)
+    for crop, pr in zip(rec["crops"], rec["preds"]):
+        PO.accumulate(counter, tuple(int(c) for c in crop), PO.one_hot(pr.astype(np.int64), 4))
+    assert np.array_equal(counter, rec["counter"])
+    assert np.array_equal(PO.vote_argmax(counter).astype(np.uint8), rec["final"])
+    m = np.arange(448 * 448).reshape(448, 448) % 4
+    r = PO.nearest_resize(m, 112)
+    assert np.array_equal(r, m[::4, ::4])  # 448 -> 112: floor(i * 4)
+
+
+@pytest.mark.skipif(not (pytest.importorskip("pathlib").Path(__file__).parent / "golden" / "vitl_e2e.npz").exists(),
+                    reason="ViT-L fixture not generated")
+def test_vitl_fixture_present(golden_dir):
+    rec = np.load(golden_dir / "vitl_e2e.npz")
+    assert rec["pred_slice"].shape == (1, 3, 112, 56)
+    assert np.isfinite(rec["pred_slice"]).all() and float(rec["grad_l2"]) > 0
