@@ -1,0 +1,485 @@
+// Fused SegGPT attention for gfx950: softmax(scale * q k^T + relh[q, kh] + relw[q, kw]) v with the decomposed
+// relative-position bias of HF:modeling_seggpt.py:268-311 applied in-kernel, forward and backward, no N x N
+// score tensor in HBM.  head_dim is fixed at 64.  One source for bf16 (32x32x16 MFMA) and f32 (32x32x2 MFMA).
+//
+// Geometry.  Tokens form an Hp x Wp grid (Wp <= 32).  A key tile is TWO grid rows, each padded to 32 slots, so
+// a 64-slot tile is two 32-row MFMA blocks: block b <-> grid row 2t + b, slot-in-block <-> kw.  Consequences:
+//   * the column part of the bias depends only on the accumulator register (16 loop-invariant values per lane)
+//     and the row part is one scalar per (query, block): the bias is the INITIAL ACCUMULATOR of the QK^T MFMAs;
+//   * "transposed" operands (V^T for PV; K^T, Q^T, dO^T in backward) live in HBM in a row-padded layout
+//     [stream][head][64][Hp*32], so every MFMA operand of every product is read along its contraction index.
+// QK^T is computed "swapped" (S^T = K Q^T): a lane owns ONE query column, so softmax statistics, the bias and
+// the O^T rescale are lane-local, and the S^T accumulator is directly the B operand of O^T += V^T P^T.
+#pragma once
+#include "common.hpp"
+
+struct AttnArgs {
+  const void* q;   // T [S*N][ld] (+ column offset applied by caller) ; head h at columns h*64..
+  const void* k;
+  const void* v;   // backward only (row-major V)
+  long ld;         // row stride in elements (3*D for the fused qkv buffer)
+  const void* vt;  // T [S][nh][64][Hp*32]
+  const void* kt;  // backward
+  const void* qt;  // backward
+  const void* dot; // backward: dO^T
+  const void* dout;  // backward: dO, T [S*N][ldo]
+  const float* relh;  // [S][nh][N][Hp]   (already divided by scale)
+  const float* relw;  // [S][nh][N][32]
+  void* out;          // fwd: O, T [S*N][ldo]
+  long ldo;
+  float* lse2;        // [S][nh][Hp*32] (row-padded)  log2-domain logsumexp of the logits
+  const float* delta; // backward: [S][nh][Hp*32]  rowsum(dO * O)
+  void* dq;  // backward outputs, T [S*N][ld] at the q/k/v column offsets of the dqkv buffer
+  void* dk;
+  void* dv;
+  float* drelh;  // [S][nh][N][Hp]   d logits / d relh (unscaled)
+  float* drelw;  // [S][nh][N][32]
+  int S, nh, N, hp, wp;
+  float scale;
+};
+
+template <int RB> DEVI int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : (row & 15); }
+
+// token index of slot `kw` of grid row `gr` (clamped to a valid token: padded slots carry weight 0)
+DEVI int slot_token(int gr, int kw, int wp) { return gr * wp + (kw < wp ? kw : wp - 1); }
+
+// Issue the LDS-DMA of one 64-row x RB-byte tile.  row_src(r) = global address of the start of tile row r.
+template <typename T, typename RowSrc>
+DEVI void dma_tile(char* lds_tile, int wave, int lane, RowSrc row_src) {
+  constexpr int RB = 64 * sizeof(T), CPR = RB / 16, RPI = 64 / CPR, IPW = 64 / (4 * RPI);
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int r = (wave * IPW + i) * RPI + lane / CPR, p = lane % CPR;
+    const char* src = row_src(r) + ((p ^ swz<RB>(r)) << 4);
+    glds16(src, lds_tile + (wave * IPW + i) * 1024);
+  }
+}
+
+template <typename T> DEVI typename Traits<T>::Chunk lds_chunk(const char* tile, int row, int chunk) {
+  constexpr int RB = 64 * sizeof(T);
+  return *(const typename Traits<T>::Chunk*)(tile + row * RB + ((chunk ^ swz<RB>(row)) << 4));
+}
+
+// A-operand chunk of a [row][64 contraction slots] LDS tile matching an S^T-layout accumulator block used as
+// the B operand.  bf16: k-step s (16 slots) of 32-slot block b, element j <-> slot 16s + 8(j>>2) + 4h + (j&3);
+// f32: k-step s (8 slots), element j <-> slot 8s + 4h + j.
+DEVI bf16x8 lds_perm_chunk(const char* tile, int row, int b, int s, int h, bf16_t) {
+  const int c0 = 4 * b + 2 * s, x = swz<128>(row);
+  const bf16x4 lo = *(const bf16x4*)(tile + row * 128 + ((c0 ^ x) << 4) + 8 * h);
+  const bf16x4 hi = *(const bf16x4*)(tile + row * 128 + (((c0 + 1) ^ x) << 4) + 8 * h);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+DEVI f32x4 lds_perm_chunk(const char* tile, int row, int b, int s, int h, float) {
+  const int c = 8 * b + 2 * s + h;
+  return *(const f32x4*)(tile + row * 256 + ((c ^ swz<256>(row)) << 4));
+}
+// The matching B-operand chunk built from accumulator block `p` (already exponentiated / scaled).
+DEVI bf16x8 acc_chunk(const f32x16& p, int s, bf16_t) {
+  bf16x8 c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = (bf16_t)p[8 * s + j];
+  return c;
+}
+DEVI f32x4 acc_chunk(const f32x16& p, int s, float) { return f32x4{p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]}; }
+
+template <typename T> struct AttnK {
+  static constexpr int EPC = Traits<T>::EPC;
+  static constexpr int KS_D = 64 / (2 * EPC);   // k-steps over head_dim for a 32x32 MFMA (4 bf16 / 8 f32)
+  static constexpr int KS_B = 32 / (2 * EPC);   // k-steps over one 32-slot block (2 bf16 / 4 f32)
+  static constexpr int RB = 64 * sizeof(T);
+  static constexpr int TILE = 64 * RB;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT][TILE]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q = min(q0 + col, a.N - 1);
+  const long sh = (long)s * a.nh + head;
+  const int npad = a.hp * 32;
+  const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
+  const char* vtbase = (const char*)a.vt + sh * 64 * npad * sizeof(T);
+
+  // loop-invariant per-lane state
+  Chunk qf[C::KS_D];
+  {
+    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+  }
+  float rw[16];
+  {
+    const float* p = a.relw + (sh * a.N + q) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
+      rw[4 * i] = v[0]; rw[4 * i + 1] = v[1]; rw[4 * i + 2] = v[2]; rw[4 * i + 3] = v[3];
+    }
+  }
+  const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
+  const float c2 = a.scale * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+
+  const int nt = a.hp >> 1;
+  auto issue = [&](int t, int buf) {
+    char* kt_l = smem + buf * 2 * C::TILE;
+    char* vt_l = kt_l + C::TILE;
+    dma_tile<T>(kt_l, wave, lane, [&](int r) {
+      return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+    });
+    dma_tile<T>(vt_l, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
+  };
+
+  f32x2 rh_next = *(const f32x2*)(relh_q);
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const f32x2 rh = rh_next;
+    wait_vm0();
+    __syncthreads();
+    if (t + 1 < nt) {
+      rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
+      issue(t + 1, buf ^ 1);
+    }
+    const char* kt_l = smem + buf * 2 * C::TILE;
+    const char* vt_l = kt_l + C::TILE;
+
+    // S^T[slot][q] = bias + K q^T       (unscaled; bias pre-divided by scale)
+    f32x16 st[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[b][r] = rw[r] + rh[b];
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks)
+        mma32(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qf[ks]);
+    }
+    // online softmax over this lane's 32 slots (+ partner half-wave)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (acc32_row(r, h) >= a.wp) st[b][r] = -INFINITY;
+        mx = fmaxf(mx, st[b][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f((st[b][r] - mn) * c2);
+        st[b][r] = p;
+        ps += p;
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    // O^T[d][q] += V^T[d][slot] P^T[slot][q]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int ks = 0; ks < C::KS_B; ++ks) {
+        const Chunk pb = acc_chunk(st[b], ks, T());
+#pragma unroll
+        for (int db = 0; db < 2; ++db) mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+      }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (q0 + col < a.N) {
+    const float inv = 1.f / l;
+    T* orow = (T*)a.out + ((long)s * a.N + q) * a.ldo + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(typename Traits<T>::Vec4*)(orow + 32 * db + 8 * i + 4 * h) =
+            pack4<T>(o[db][4 * i] * inv, o[db][4 * i + 1] * inv, o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
+    if (h == 0 && a.lse2) a.lse2[sh * npad + (q / a.wp) * 32 + (q % a.wp)] = m * c2 + log2f(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dQ
+// Query-stationary, same swapped layout as forward.  Per key tile: S^T (bias as initial accumulator) ->
+// P^T = exp2(S^T c2 - lse2) -> dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.
+// The rel-pos gradients fall out of the layout: d relw[q][kw] accumulates per accumulator REGISTER over the
+// whole key loop (register <-> kw), d relh[q][2t+b] is the per-block sum.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT][TILE]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q = min(q0 + col, a.N - 1);
+  const int qpad = (q / a.wp) * 32 + (q % a.wp);
+  const long sh = (long)s * a.nh + head;
+  const int npad = a.hp * 32;
+  const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
+  const char* vbase = (const char*)a.v + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
+  const char* ktbase = (const char*)a.kt + sh * 64 * npad * sizeof(T);
+
+  Chunk qf[C::KS_D], dof[C::KS_D];
+  {
+    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
+    const char* drow = (const char*)a.dout + (((long)s * a.N + q) * a.ldo + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) {
+      qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+      dof[ks] = *(const Chunk*)(drow + (2 * ks + h) * 16);
+    }
+  }
+  float rw[16], drw[16];
+  {
+    const float* p = a.relw + (sh * a.N + q) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
+      rw[4 * i] = v[0]; rw[4 * i + 1] = v[1]; rw[4 * i + 2] = v[2]; rw[4 * i + 3] = v[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) drw[i] = 0.f;
+  }
+  const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
+  float* drelh_q = a.drelh + (sh * a.N + q) * a.hp;
+  const float c2 = a.scale * 1.44269504088896340736f;
+  const float lse = a.lse2[sh * npad + qpad];
+  const float dl = a.delta[sh * npad + qpad];
+  f32x16 dqt[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+
+  const int nt = a.hp >> 1;
+  auto issue = [&](int t, int buf) {
+    char* k_l = smem + buf * 3 * C::TILE;
+    dma_tile<T>(k_l, wave, lane, [&](int r) {
+      return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+    });
+    dma_tile<T>(k_l + C::TILE, wave, lane, [&](int r) {
+      return vbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+    });
+    dma_tile<T>(k_l + 2 * C::TILE, wave, lane, [&](int r) { return ktbase + ((long)r * npad + t * 64) * sizeof(T); });
+  };
+
+  f32x2 rh_next = *(const f32x2*)(relh_q);
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const f32x2 rh = rh_next;
+    wait_vm0();
+    __syncthreads();
+    if (t + 1 < nt) {
+      rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
+      issue(t + 1, buf ^ 1);
+    }
+    const char* k_l = smem + buf * 3 * C::TILE;
+    const char* v_l = k_l + C::TILE;
+    const char* kt_l = k_l + 2 * C::TILE;
+    float drh[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = rw[r] + rh[b]; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) {
+        mma32(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qf[ks]);
+        mma32(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dof[ks]);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = acc32_row(r, h) < a.wp;
+        const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lse) : 0.f;
+        const float ds = ok ? p * (dp[r] - dl) : 0.f;
+        st[r] = ds;
+        drw[r] += ds;
+        sum += ds;
+      }
+      drh[b] = sum + __shfl_xor(sum, 32, 64);
+#pragma unroll
+      for (int ks = 0; ks < C::KS_B; ++ks) {
+        const Chunk db_ = acc_chunk(st, ks, T());
+#pragma unroll
+        for (int d = 0; d < 2; ++d) mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
+      }
+    }
+    if (h == 0 && q0 + col < a.N) *(f32x2*)(drelh_q + 2 * t) = f32x2{drh[0], drh[1]};
+  }
+  if (q0 + col < a.N) {
+    T* orow = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(typename Traits<T>::Vec4*)(orow + 32 * d + 8 * i + 4 * h) =
+            pack4<T>(dqt[d][4 * i] * a.scale, dqt[d][4 * i + 1] * a.scale, dqt[d][4 * i + 2] * a.scale,
+                     dqt[d][4 * i + 3] * a.scale);
+    float* p = a.drelw + (sh * a.N + q) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(f32x4*)(p + 8 * i + 4 * h) = f32x4{drw[4 * i], drw[4 * i + 1], drw[4 * i + 2], drw[4 * i + 3]};
+  }
+}
+
+// ------------------------------------------------------------------------------------- backward: dK, dV
+// Key-stationary: each wave owns one key tile (64 slots = 2 grid rows) and keeps dK^T, dV^T for it in
+// accumulators while the workgroup streams query tiles (2 grid rows of Q, dO, Q^T, dO^T) through LDS.
+// Here the KEY is on the lane (S = Q K^T un-swapped), so P and dS accumulators are the B operands of
+// dV^T += dO^T P and dK^T += Q^T dS.  Bias / lse2 / delta arrive in query-slot-major ("T") layouts:
+//   relwT [S][nh][32 kw][Hp*32],  relhT [S][nh][Hp key rows][Hp*32],  lse2/delta [S][nh][Hp*32].
+struct AttnBwdKvArgs {
+  const void* k; const void* v; const void* q; const void* dout;  // row-major T (q/k/v with ld, dout with ldo)
+  const void* qt; const void* dot;                                // [S][nh][64][Hp*32]
+  long ld, ldo;
+  const float* relwT; const float* relhT; const float* lse2; const float* delta;
+  void* dk; void* dv;  // T, row stride ld
+  int S, nh, N, hp, wp;
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][Q | dO | QT | dOT][TILE]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int nt = a.hp >> 1;
+  const int kt = min(blockIdx.x * 4 + wave, nt - 1);  // this wave's key tile (clamped: duplicates do not store)
+  const bool wave_valid = blockIdx.x * 4 + wave < nt;
+  const long sh = (long)s * a.nh + head;
+  const int npad = a.hp * 32;
+  const char* qbase = (const char*)a.q + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
+  const char* dobase = (const char*)a.dout + ((long)s * a.N * a.ldo + head * 64) * sizeof(T);
+  const char* qtbase = (const char*)a.qt + sh * 64 * npad * sizeof(T);
+  const char* dotbase = (const char*)a.dot + sh * 64 * npad * sizeof(T);
+
+  // K, V fragments of this wave's 64 key slots (B operands), loop-invariant
+  Chunk kf[2][C::KS_D], vf[2][C::KS_D];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const long tok = (long)s * a.N + slot_token(2 * kt + b, col, a.wp);
+    const char* krow = (const char*)a.k + (tok * a.ld + head * 64) * sizeof(T);
+    const char* vrow = (const char*)a.v + (tok * a.ld + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) {
+      kf[b][ks] = *(const Chunk*)(krow + (2 * ks + h) * 16);
+      vf[b][ks] = *(const Chunk*)(vrow + (2 * ks + h) * 16);
+    }
+  }
+  const float c2 = a.scale * 1.44269504088896340736f;
+  const bool key_valid = col < a.wp;
+  f32x16 dkt[2][2], dvt[2][2];  // [d block][key block]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    dkt[0][0][i] = dkt[0][1][i] = dkt[1][0][i] = dkt[1][1][i] = 0.f;
+    dvt[0][0][i] = dvt[0][1][i] = dvt[1][0][i] = dvt[1][1][i] = 0.f;
+  }
+  const float* relwT = a.relwT + (sh * 32 + col) * npad;  // + q slot
+  const float* relhT0 = a.relhT + (sh * a.hp + 2 * kt) * npad;
+  const float* lse2 = a.lse2 + sh * npad;
+  const float* delta = a.delta + sh * npad;
+
+  auto issue = [&](int t, int buf) {
+    char* q_l = smem + buf * 4 * C::TILE;
+    dma_tile<T>(q_l, wave, lane, [&](int r) {
+      return qbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+    });
+    dma_tile<T>(q_l + C::TILE, wave, lane, [&](int r) {
+      return dobase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ldo * sizeof(T);
+    });
+    dma_tile<T>(q_l + 2 * C::TILE, wave, lane, [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_tile<T>(q_l + 3 * C::TILE, wave, lane, [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
+  };
+
+  issue(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    // per-row statistics of the 64 query slots of this step (issued BEFORE the next DMA: vmcnt is in-order)
+    f32x4 lsev[2][4], dlv[2][4], rwv[2][4], rhv[2][2][4];
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int qs = t * 64 + qa * 32 + 8 * i + 4 * h;  // padded q slot of registers 4i..4i+3
+        lsev[qa][i] = *(const f32x4*)(lse2 + qs);
+        dlv[qa][i] = *(const f32x4*)(delta + qs);
+        rwv[qa][i] = *(const f32x4*)(relwT + qs);
+        rhv[qa][0][i] = *(const f32x4*)(relhT0 + qs);
+        rhv[qa][1][i] = *(const f32x4*)(relhT0 + npad + qs);
+      }
+    wait_vm0();
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1, buf ^ 1);
+    const char* q_l = smem + buf * 4 * C::TILE;
+    const char* do_l = q_l + C::TILE;
+    const char* qt_l = q_l + 2 * C::TILE;
+    const char* dot_l = q_l + 3 * C::TILE;
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = rwv[qa][r >> 2][r & 3] + rhv[qa][b][r >> 2][r & 3]; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS_D; ++ks) {
+          mma32(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kf[b][ks]);
+          mma32(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vf[b][ks]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = key_valid && acc32_row(r, h) < a.wp;
+          const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lsev[qa][r >> 2][r & 3]) : 0.f;
+          st[r] = p;                                                   // P
+          dp[r] = ok ? p * (dp[r] - dlv[qa][r >> 2][r & 3]) : 0.f;      // dS
+        }
+#pragma unroll
+        for (int ks = 0; ks < C::KS_B; ++ks) {
+          const Chunk pb = acc_chunk(st, ks, T());
+          const Chunk dsb = acc_chunk(dp, ks, T());
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            mma32(dvt[d][b], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
+            mma32(dkt[d][b], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
+          }
+        }
+      }
+    }
+  }
+  if (wave_valid && key_valid) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const long tok = (long)s * a.N + (2 * kt + b) * a.wp + col;
+      T* dkrow = (T*)a.dk + tok * a.ld + head * 64;
+      T* dvrow = (T*)a.dv + tok * a.ld + head * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          *(typename Traits<T>::Vec4*)(dkrow + 32 * d + 8 * i + 4 * h) =
+              pack4<T>(dkt[d][b][4 * i] * a.scale, dkt[d][b][4 * i + 1] * a.scale, dkt[d][b][4 * i + 2] * a.scale,
+                       dkt[d][b][4 * i + 3] * a.scale);
+          *(typename Traits<T>::Vec4*)(dvrow + 32 * d + 8 * i + 4 * h) =
+              pack4<T>(dvt[d][b][4 * i], dvt[d][b][4 * i + 1], dvt[d][b][4 * i + 2], dvt[d][b][4 * i + 3]);
+        }
+    }
+  }
+}

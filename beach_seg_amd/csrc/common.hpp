@@ -1,0 +1,100 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the SegGPT hot path.
+// One source serves two activation dtypes: T = __bf16 (throughput mode, bf16 MFMA) and T = float
+// (parity mode, exact-f32 MFMA).  Both see the same BYTE geometry: a fragment is one 16-byte chunk
+// per lane (8 bf16 or 4 f32); an LDS tile row is 128 bytes = 8 chunks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define DEVI __device__ __forceinline__
+
+template <typename T> struct Traits;
+template <> struct Traits<bf16_t> {
+  typedef bf16x8 Chunk;
+  typedef bf16x4 Vec4;
+  static constexpr int EPC = 8;  // elements per 16-byte chunk
+};
+template <> struct Traits<float> {
+  typedef f32x4 Chunk;
+  typedef f32x4 Vec4;
+  static constexpr int EPC = 4;
+};
+
+// ---- MFMA wrappers.  16x16 tile: lane l holds row/col (l & 15) and chunk (l >> 4) of a 4-chunk K step.
+//      32x32 tile: lane l holds row/col (l & 31) and chunk (l >> 5) of a 2-chunk K step.
+//      f32 path: element j of every lane's chunk forms one k-slice of an exact-f32 MFMA, so the fragment
+//      addressing is identical to the bf16 path.
+DEVI void mma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+DEVI void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+}
+DEVI void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+DEVI void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+}
+
+// 32x32 accumulator: register r of lane l is row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31.
+DEVI int acc32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ---- conversions
+DEVI float to_f32(float x) { return x; }
+DEVI float to_f32(bf16_t x) { return (float)x; }
+template <typename T> DEVI T from_f32(float x);
+template <> DEVI float from_f32<float>(float x) { return x; }
+template <> DEVI bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+template <typename T> DEVI typename Traits<T>::Vec4 pack4(float a, float b, float c, float d);
+template <> DEVI f32x4 pack4<float>(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
+template <> DEVI bf16x4 pack4<bf16_t>(float a, float b, float c, float d) {
+  return bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+
+// chunk from 8 (bf16) or 4 (f32) floats held in two f32x4 (second ignored for f32)
+DEVI void chunk_from_f32(bf16x8& c, const float* v) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = (bf16_t)v[j];
+}
+
+// ---- async global -> LDS copy of one 16-byte chunk per lane (LDS-DMA).  `lds_wave_base` must be
+//      wave-uniform; lane l lands at lds_wave_base + 16 * l.
+DEVI void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- wave-level reductions (64 lanes)
+DEVI float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// exact erf GELU (HF ACT2FN["gelu"] == torch F.gelu default) and its derivative
+DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+DEVI float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware remap of a 1-D grid: the dispatcher deals consecutive block ids round-robin over the 8 XCDs,
+// so give each XCD a contiguous span of logical tiles (bijective for any grid size).
+DEVI int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}

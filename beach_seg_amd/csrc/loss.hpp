@@ -1,0 +1,174 @@
+// Reference wrapper arithmetic on device (all fp32 / integer, HBM-bound):
+//   masked smooth-L1 loss + its gradient   (/root/reference/src/model.py:45-64, incl. the B x B broadcast of :61)
+//   palette arg-min decode                  (src/model.py:155-175)  -- bit-exact vs torch: no FMA contraction
+//   AdamW on the prompt pixels              (src/model.py:398, torch.optim.AdamW defaults)
+//   predict-loop glue: nearest resize + one-hot vote + arg-max (src/predict.py:259-260, 120-159, 100)
+#pragma once
+#include "common.hpp"
+
+// counts[p] = sum_i yes_i[p] over the batch (fp32), total[0] += number of kept pixels (exact integer)
+__global__ void loss_prep_kernel(const uint8_t* __restrict__ yes, float* __restrict__ counts,
+                                 unsigned long long* __restrict__ total, int B, long hw) {
+  const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  unsigned c = 0;
+  if (p < hw)
+    for (int i = 0; i < B; ++i) c += yes[(long)i * hw + p] ? 1u : 0u;
+  if (p < hw) counts[p] = (float)c;
+  // wave-aggregate then one atomic per wave
+  unsigned long long w = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+  if ((threadIdx.x & 63) == 0 && w) atomicAdd(total, w);
+}
+
+// pred fp32 (B,3,2H,W); labels fp32 (B,3,H,W); yes u8 (B,H,W).  variant 0 = reference (weight = counts[p]),
+// 1 = per-sample (weight = yes_j[p]).  Writes dpred (B,3,2H,W) (top half zero) and one partial sum per block.
+__global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ labels,
+                                                            const uint8_t* __restrict__ yes,
+                                                            const float* __restrict__ counts,
+                                                            const unsigned long long* __restrict__ total,
+                                                            float* __restrict__ dpred, float* __restrict__ partial,
+                                                            int B, int H, int W, float beta, int variant) {
+  const long hw = (long)H * W, n = (long)B * 3 * 2 * hw;
+  const float denom = 3.f * (float)(*total);
+  const float inv = 1.f / denom;
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long bc = i / (2 * hw), r = i % (2 * hw);
+    float g = 0.f;
+    if (r >= hw) {
+      const long p = r - hw;
+      const int b = bc / 3;
+      const float wgt = variant == 0 ? counts[p] : (yes[(long)b * hw + p] ? 1.f : 0.f);
+      if (wgt != 0.f) {
+        const float d = pred[i] - labels[bc * hw + p];
+        const float ad = fabsf(d);
+        float l, dl;
+        if (ad < beta) { l = 0.5f * d * d / beta; dl = d / beta; }
+        else { l = ad - 0.5f * beta; dl = d > 0.f ? 1.f : -1.f; }
+        acc += wgt * l;
+        g = wgt * dl * inv;
+      }
+    }
+    if (dpred) dpred[i] = g;
+  }
+  acc = wave_sum(acc);
+  __shared__ float ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ partial, int n,
+                                     const unsigned long long* __restrict__ total, float* __restrict__ loss) {
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc / (3.f * (float)(*total));
+}
+
+// arg-min over K palette colours of sum_c (pred[c] - pal[k][c])^2 on the bottom half; first index wins ties.
+// The products and sums are kept as separate IEEE operations in torch's order ((d0^2 + d1^2) + d2^2).
+__global__ void decode_argmin_kernel(const float* __restrict__ pred, const float* __restrict__ pal_norm,
+                                     long long* __restrict__ out_i64, uint8_t* __restrict__ out_u8, int B, int H,
+                                     int W, int K) {
+  const long hw = (long)H * W, n = (long)B * hw;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = i / hw;
+  const long p = i % hw;
+  const float* pr = pred + (long)b * 3 * 2 * hw + hw + p;
+  const float v0 = pr[0], v1 = pr[2 * hw], v2 = pr[4 * hw];
+  int best = 0;
+  float bd = INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float* c = pal_norm + ((long)b * K + k) * 3;
+    const float d0 = __fsub_rn(v0, c[0]), d1 = __fsub_rn(v1, c[1]), d2 = __fsub_rn(v2, c[2]);
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+    if (d < bd) { bd = d; best = k; }
+  }
+  if (out_i64) out_i64[i] = best;
+  if (out_u8) out_u8[i] = (uint8_t)best;
+}
+
+// AdamW step on the active prompts (torch.optim.AdamW: decoupled decay, bias correction, eps outside sqrt-hat).
+// idx[a] = prompt row; step_sizes[a] = lr / (1 - beta1^t), bc2_sqrts[a] = sqrt(1 - beta2^t) with t that
+// parameter's own step count (torch keeps one `step` per Parameter and skips Parameters without a gradient);
+// both are computed on the host in double, as torch does.
+__global__ void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                             float* __restrict__ v, const int* __restrict__ idx,
+                             const float* __restrict__ step_sizes, const float* __restrict__ bc2_sqrts, long n,
+                             float lr, float beta1, float beta2, float eps, float wd, float grad_scale) {
+  const int row = idx[blockIdx.y];
+  const float step_size = step_sizes[blockIdx.y], bc2s = bc2_sqrts[blockIdx.y];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long o = (long)row * n + i;
+    const float g = grad[o] * grad_scale;
+    float p = param[o] * (1.f - lr * wd);
+    const float mm = m[o] + (1.f - beta1) * (g - m[o]);  // lerp, as torch
+    const float vv = beta2 * v[o] + (1.f - beta2) * g * g;
+    m[o] = mm;
+    v[o] = vv;
+    p -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+    param[o] = p;
+  }
+}
+
+// grad_param[idx[b]] += grad_prompt_pixels[b] / std[c]   (backward of Normalize + stack; duplicates accumulate)
+__global__ void prompt_grad_scatter_kernel(const float* __restrict__ gpix, float* __restrict__ gparam,
+                                           const int* __restrict__ idx, int B, long chw, long hw, float is0,
+                                           float is1, float is2) {
+  const long n = (long)B * chw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / chw;
+    const long r = i % chw;
+    const int c = r / hw;
+    atomicAdd(gparam + (long)idx[b] * chw + r, gpix[i] * (c == 0 ? is0 : c == 1 ? is1 : is2));
+  }
+}
+
+// prompt_pixels[b] = (param[idx[b]] - mean[c]) / std[c]   (stack + Normalize, src/model.py:197, data.py:224)
+__global__ void prompt_gather_kernel(const float* __restrict__ param, float* __restrict__ out,
+                                     const int* __restrict__ idx, int B, long chw, long hw, float m0, float m1,
+                                     float m2, float s0, float s1, float s2) {
+  const long n = (long)B * chw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / chw;
+    const long r = i % chw;
+    const int c = r / hw;
+    const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, sd = c == 0 ? s0 : c == 1 ? s1 : s2;
+    out[i] = (param[(long)idx[b] * chw + r] - mean) / sd;
+  }
+}
+
+// Predict glue: nearest-resize the (hin x win) class mask to (crop x crop), clip the window to the mosaic, add
+// one vote to counter[y][x][cls] (uint8, wraps like numpy).  One thread per destination pixel of one crop.
+__global__ void vote_paste_kernel(const uint8_t* __restrict__ masks, uint8_t* __restrict__ counter,
+                                  const int* __restrict__ crops, int ncrops, int hin, int win, int crop, int mh,
+                                  int mw, int K) {
+  const int ci = blockIdx.y;
+  const int xmin = crops[4 * ci], ymin = crops[4 * ci + 1], xmax = crops[4 * ci + 2], ymax = crops[4 * ci + 3];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= crop * crop) return;
+  const int sy = t / crop, sx = t % crop;
+  if (sy >= ymax - ymin || sx >= xmax - xmin) return;
+  const int y = ymin + sy, x = xmin + sx;
+  if (y < 0 || y >= mh || x < 0 || x >= mw) return;
+  const int iy = min((int)floorf(sy * ((float)hin / crop)), hin - 1);
+  const int ix = min((int)floorf(sx * ((float)win / crop)), win - 1);
+  const int cls = masks[((long)ci * hin + iy) * win + ix];
+  uint8_t* c = counter + ((long)y * mw + x) * K + cls;
+  *c = (uint8_t)(*c + 1);  // crops of one launch must not overlap (callers launch overlapping crops separately)
+}
+
+__global__ void vote_argmax_kernel(const uint8_t* __restrict__ counter, uint8_t* __restrict__ out, long n, int K) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int best = 0, bv = counter[i * K];
+  for (int k = 1; k < K; ++k) {
+    const int v = counter[i * K + k];
+    if (v > bv) { bv = v; best = k; }
+  }
+  out[i] = (uint8_t)best;
+}

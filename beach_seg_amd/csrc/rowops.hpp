@@ -1,0 +1,269 @@
+// HBM-bound row kernels of the SegGPT hot path (wavefront reductions, vectorised 16-byte accesses):
+// LayerNorm fwd/bwd (HF:397-398, 444, 475-476), stream merge (HF:470-473), canvas patch gather (HF:705-710 +
+// HF:108 as an im2col-free k=s=16 gather), decomposed rel-pos tables (HF:236-311) and their gradient, head
+// transposes, attention delta.
+#pragma once
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row; x fp32 [rows][D], D <= 2048; y = T [rows][ldy] (column offset applied by the caller).
+// Branch-free: lanes past D load column 0 and contribute zeros.
+struct LnRow {
+  f32x4 v[8];
+  float mean, rstd;
+  DEVI void load(const float* xr, int lane, int D, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const bool ok = c < D;
+      const f32x4 t = *(const f32x4*)(xr + (ok ? c : 0));
+      v[i] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = (i * 64 + lane) * 4 < D;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = ok ? v[i][j] - mean : 0.f;
+        q += v[i][j] * v[i][j];
+      }
+    }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 4) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, T* __restrict__ y, long ldy,
+                                                         int rows, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  LnRow r;
+  r.load(x + (long)row * D, lane, D, eps);
+  T* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+      *(typename Traits<T>::Vec4*)(yr + c) =
+          pack4<T>(r.v[i][0] * r.rstd * g[0] + b[0], r.v[i][1] * r.rstd * g[1] + b[1],
+                   r.v[i][2] * r.rstd * g[2] + b[2], r.v[i][3] * r.rstd * g[3] + b[3]);
+    }
+  }
+}
+
+// dx[row] = dx_in[row] * in_scale + LN'(x[row]) applied to dy[row]; optional T copy for the next dgrad GEMM.
+// Statistics are recomputed from x (read anyway), nothing is saved by the forward.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* dx_in,
+                                                         float in_scale, float* dx_out, T* dx_t, int rows, int D,
+                                                         float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  LnRow r;
+  r.load(x + (long)row * D, lane, D, eps);
+  const T* dyr = dy + (long)row * lddy;
+  f32x4 g[8];
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const bool ok = c < D;
+    const typename Traits<T>::Vec4 d = *(const typename Traits<T>::Vec4*)(dyr + (ok ? c : 0));
+    const f32x4 gm = *(const f32x4*)(gamma + (ok ? c : 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r.v[i][j] *= r.rstd;  // xhat (0 past D)
+      g[i][j] = ok ? to_f32(d[j]) * gm[j] : 0.f;
+      sg += g[i][j];
+      sgx += g[i][j] * r.v[i][j];
+    }
+  }
+  const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = r.rstd * (g[i][j] - mg - r.v[i][j] * mgx);
+      if (dx_in) {
+        const f32x4 p = *(const f32x4*)(dx_in + (long)row * D + c);
+        o += p * in_scale;
+      }
+      *(f32x4*)(dx_out + (long)row * D + c) = o;
+      if (dx_t) *(typename Traits<T>::Vec4*)(dx_t + (long)row * D + c) = pack4<T>(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// out[b] = (x[b] + x[B + b]) * 0.5     (HF:470-473), n4 = elements/4 of one half
+__global__ void merge_halves_kernel(const float* __restrict__ x, float* __restrict__ out, long n4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = ((const f32x4*)x)[i], b = ((const f32x4*)x)[i + n4];
+    ((f32x4*)out)[i] = (a + b) * 0.5f;
+  }
+}
+
+// fp32 -> T copy (used when a fp32 gradient stream feeds a dgrad GEMM without a LayerNorm in between)
+template <typename T>
+__global__ void cast_rows_kernel(const float* x, T* y, long n4, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = ((const f32x4*)x)[i] * scale;
+    ((typename Traits<T>::Vec4*)y)[i] = pack4<T>(a[0], a[1], a[2], a[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------- canvas patch gather
+// A[m][k], m = s*N + t, k = c*256 + i*16 + j.  Stream s < B: image canvas = cat(prompt image, query image) on H
+// (HF:705); s >= B: mask canvas, top half = prompt mask, bottom half is masked out by the default
+// bool_masked_pos (HF:902-909) and never read: those rows are written as zeros (the token table supplies
+// mask_token there).  One thread per (row, c, i): 64 B in, 16 elements out.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ prompt_img, const float* __restrict__ query_img,
+                                const float* __restrict__ prompt_mask, T* __restrict__ A, int B, int hp, int wp) {
+  const int N = hp * wp, hh = hp / 2;
+  const long total = (long)2 * B * N * 48;
+  const int Hh = hh * 16, W = wp * 16;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int ci = idx % 48;
+    const long m = idx / 48;
+    const int c = ci / 16, i = ci % 16;
+    const int s = m / N, t = m % N, ph = t / wp, pw = t % wp;
+    const float* src = nullptr;
+    if (s < B) src = (ph < hh ? prompt_img : query_img) + (((long)s * 3 + c) * Hh + (ph % hh) * 16 + i) * W + pw * 16;
+    else if (ph < hh) src = prompt_mask + (((long)(s - B) * 3 + c) * Hh + ph * 16 + i) * W + pw * 16;
+    T* dst = A + m * 768 + c * 256 + i * 16;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (src) v = *(const f32x4*)(src + 4 * j4);
+      *(typename Traits<T>::Vec4*)(dst + 4 * j4) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------- decomposed rel-pos tables
+// relh[sh][q][kh] = q . rel_pos_h[qh - kh + Hp - 1] / scale,  relw[sh][q][kw] likewise (unscaled q, HF:326-329).
+// Also the query-slot-major copies used by the dK/dV kernel when `relhT` != nullptr.
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_fwd_kernel(const T* __restrict__ qkv, long ld,
+                                                          const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w, float* __restrict__ relh,
+                                                          float* __restrict__ relw, float* relhT, float* relwT, int N,
+                                                          int hp, int wp, int nh, float inv_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = (float*)smem;             // [64][65]
+  float* rh = qs + 64 * 65;             // [2hp-1][65]
+  float* rw = rh + (2 * hp - 1) * 65;   // [2wp-1][65]
+  const int head = blockIdx.y, s = blockIdx.z, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  const long sh = (long)s * nh + head;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int qi = i >> 6, c = i & 63, q = min(q0 + qi, N - 1);
+    qs[qi * 65 + c] = to_f32(qkv[((long)s * N + q) * ld + head * 64 + c]);
+  }
+  for (int i = tid; i < (2 * hp - 1) * 64; i += 256) rh[(i >> 6) * 65 + (i & 63)] = rel_h[i];
+  for (int i = tid; i < (2 * wp - 1) * 64; i += 256) rw[(i >> 6) * 65 + (i & 63)] = rel_w[i];
+  __syncthreads();
+  const int per = hp + wp, npad = hp * 32;
+  for (int i = tid; i < 64 * per; i += 256) {
+    const int qi = i / per, j = i % per, q = q0 + qi;
+    if (q >= N) continue;
+    const int qh = q / wp, qw = q % wp;
+    const float* r = j < hp ? rh + (qh - j + hp - 1) * 65 : rw + (qw - (j - hp) + wp - 1) * 65;
+    const float* qq = qs + qi * 65;
+    float acc = 0.f;
+#pragma unroll 16
+    for (int c = 0; c < 64; ++c) acc += qq[c] * r[c];
+    acc *= inv_scale;
+    const int qpad = qh * 32 + qw;
+    if (j < hp) {
+      relh[(sh * N + q) * hp + j] = acc;
+      if (relhT) relhT[(sh * hp + j) * npad + qpad] = acc;
+    } else {
+      relw[(sh * N + q) * 32 + (j - hp)] = acc;
+      if (relwT) relwT[(sh * 32 + (j - hp)) * npad + qpad] = acc;
+    }
+  }
+}
+
+// dq[q][c] += sum_kh drelh[q][kh] Rh[qh-kh+Hp-1][c] + sum_kw drelw[q][kw] Rw[qw-kw+Wp-1][c]
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_bwd_kernel(T* __restrict__ dq, long ld, const float* __restrict__ rel_h,
+                                                          const float* __restrict__ rel_w,
+                                                          const float* __restrict__ drelh,
+                                                          const float* __restrict__ drelw, int N, int hp, int wp,
+                                                          int nh) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rh = (float*)smem;            // [2hp-1][64]
+  float* rw = rh + (2 * hp - 1) * 64;  // [2wp-1][64]
+  const int head = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
+  const long sh = (long)s * nh + head;
+  for (int i = tid; i < (2 * hp - 1) * 64; i += 256) rh[i] = rel_h[i];
+  for (int i = tid; i < (2 * wp - 1) * 64; i += 256) rw[i] = rel_w[i];
+  __syncthreads();
+  const int q = blockIdx.x * 64 + (tid >> 2), c0 = (tid & 3) * 16;
+  if (q >= N) return;
+  const int qh = q / wp, qw = q % wp;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  const float* dh = drelh + (sh * N + q) * hp;
+  const float* dw = drelw + (sh * N + q) * 32;
+  for (int kh = 0; kh < hp; ++kh) {
+    const float g = dh[kh];
+    const float* r = rh + (qh - kh + hp - 1) * 64 + c0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] += g * r[c];
+  }
+  for (int kw = 0; kw < wp; ++kw) {
+    const float g = dw[kw];
+    const float* r = rw + (qw - kw + wp - 1) * 64 + c0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] += g * r[c];
+  }
+  T* p = dq + ((long)s * N + q) * ld + head * 64 + c0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) p[c] = from_f32<T>(to_f32(p[c]) + acc[c]);
+}
+
+// ------------------------------------------------------------------------------------- head transposes
+// X [S*N][ld] (head columns) -> XT [S][nh][64][Hp*32]; one block per (grid row, head, stream); padded slots = 0
+template <typename T>
+__global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict__ x, long ld, T* __restrict__ xt,
+                                                              int N, int hp, int wp, int nh) {
+  __shared__ float tile[32][65];
+  const int gr = blockIdx.x, head = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int kw = i >> 6, d = i & 63;
+    tile[kw][d] = kw < wp ? to_f32(x[((long)s * N + gr * wp + kw) * ld + head * 64 + d]) : 0.f;
+  }
+  __syncthreads();
+  const int d = tid >> 2, k0 = (tid & 3) * 8;
+  T* dst = xt + (((long)s * nh + head) * 64 + d) * (hp * 32) + gr * 32 + k0;
+  *(typename Traits<T>::Vec4*)dst = pack4<T>(tile[k0][d], tile[k0 + 1][d], tile[k0 + 2][d], tile[k0 + 3][d]);
+  *(typename Traits<T>::Vec4*)(dst + 4) = pack4<T>(tile[k0 + 4][d], tile[k0 + 5][d], tile[k0 + 6][d], tile[k0 + 7][d]);
+}
+
+// delta[sh][qpad] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one wave per token row
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ o, long ld,
+                                                          float* __restrict__ delta, int S, int N, int hp, int wp,
+                                                          int nh) {
+  const long row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)S * N) return;
+  const int s = row / N, q = row % N;
+  const int qpad = (q / wp) * 32 + q % wp;
+  for (int h = 0; h < nh; ++h) {
+    const float v = to_f32(dout[row * ld + h * 64 + lane]) * to_f32(o[row * ld + h * 64 + lane]);
+    const float t = wave_sum(v);
+    if (lane == 0) delta[((long)s * nh + h) * (hp * 32) + qpad] = t;
+  }
+}

@@ -1,0 +1,590 @@
+// Host side of the C ABI (include/beach_seg_amd.h): workspace plan + launch sequences of the SegGPT forward
+// (HF:modeling_seggpt.py:831-951) and of the dgrad-only backward the reference obtains from autograd
+// (src/model.py:233-269 with every weight frozen, src/util/ml_util.py:9-10).  No allocation, no
+// synchronisation: every launch goes to the caller's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/beach_seg_amd.h"
+#include "attention.hpp"
+#include "decoder.hpp"
+#include "gemm.hpp"
+#include "loss.hpp"
+#include "rowops.hpp"
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define CHECK_LAUNCH()                                                        \
+  do {                                                                        \
+    hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) return fail("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+  } while (0)
+
+struct Region { std::string name; int layer; size_t off, bytes; };
+struct Plan {
+  std::vector<Region> r;
+  size_t total = 0;
+  void add(const char* name, int layer, size_t bytes) {
+    r.push_back({name, layer, total, bytes});
+    total += (bytes + 255) & ~(size_t)255;
+  }
+  const Region* find(const char* name, int layer) const {
+    for (auto& x : r) if (x.name == name && x.layer == layer) return &x;
+    return nullptr;
+  }
+};
+
+struct bsg_model {
+  bsg_config c;
+  std::vector<const void*> w;
+  int hp, wp, N, npad, es;
+  const void* gw(int i) const { return w[i]; }
+  const void* lw(int l, int i) const { return w[BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * l + i]; }
+  bool is_tap(int l, int* ti) const {
+    for (int i = 0; i < c.num_taps; ++i) if (c.taps[i] == l) { *ti = i; return true; }
+    return false;
+  }
+  int streams(int l, int B) const { return l <= c.merge_index ? 2 * B : B; }
+};
+
+static Plan make_plan(const bsg_model* m, int B, int train) {
+  Plan p;
+  const size_t es = m->es, N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads,
+               mlp = m->c.mlp_dim, npad = m->npad, hp = m->hp, nt = m->c.num_taps;
+  const size_t HW = (size_t)m->c.canvas_h * m->c.canvas_w;
+  const size_t r2 = 2 * (size_t)B * N, r1 = (size_t)B * N;
+  p.add("patch_a", -1, r2 * 768 * es);
+  if (train) {
+    for (size_t l = 0; l < L; ++l) {
+      const size_t rows = (size_t)m->streams(l, B) * N, S = m->streams(l, B);
+      p.add("x_in", l, rows * D * 4);
+      p.add("x_mid", l, rows * D * 4);
+      p.add("qkv", l, rows * 3 * D * es);
+      p.add("attn_o", l, rows * D * es);
+      p.add("lse2", l, S * nh * npad * 4);
+      p.add("h_pre", l, rows * mlp * es);
+    }
+    p.add("x_in", L, r1 * D * 4);
+    p.add("x_tmp", -1, r2 * D * 4);
+    p.add("conv_out", -1, (size_t)B * HW * 64 * es);
+  } else {
+    p.add("x_a", -1, r2 * D * 4);
+    p.add("x_b", -1, r2 * D * 4);
+    p.add("x_c", -1, r2 * D * 4);
+    p.add("qkv", -1, r2 * 3 * D * es);
+    p.add("attn_o", -1, r2 * D * es);
+    p.add("lse2", -1, 2 * (size_t)B * nh * npad * 4);
+  }
+  p.add("ln_out", -1, r2 * D * es);
+  p.add("h_act", -1, r2 * mlp * es);
+  p.add("vt", -1, 2 * (size_t)B * nh * 64 * npad * es);
+  p.add("relh", -1, 2 * (size_t)B * nh * N * hp * 4);
+  p.add("relw", -1, 2 * (size_t)B * nh * N * 32 * 4);
+  p.add("taps", -1, r1 * nt * D * es);
+  p.add("feat", -1, (size_t)B * HW * 64 * es);
+  if (train) {
+    p.add("feat2", -1, (size_t)B * HW * 64 * es);
+    p.add("dtaps", -1, r1 * nt * D * es);
+    p.add("dx", -1, r1 * D * 4);
+    p.add("dx_t", -1, r1 * D * es);
+    p.add("dh", -1, r1 * mlp * es);
+    p.add("dn_a", -1, r1 * D * es);
+    p.add("dn_b", -1, r1 * D * es);
+    p.add("dqkv", -1, r1 * 3 * D * es);
+    p.add("kt", -1, (size_t)B * nh * 64 * npad * es);
+    p.add("qt", -1, (size_t)B * nh * 64 * npad * es);
+    p.add("dot", -1, (size_t)B * nh * 64 * npad * es);
+    p.add("delta", -1, (size_t)B * nh * npad * 4);
+    p.add("drelh", -1, (size_t)B * nh * N * hp * 4);
+    p.add("drelw", -1, (size_t)B * nh * N * 32 * 4);
+    p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
+    p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
+  }
+  return p;
+}
+
+template <typename K> static void allow_lds(K kernel, int bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// ------------------------------------------------------------------------------------------- launch helpers
+template <typename T, int AM, int EPI> static void gemm(GemmArgs g, hipStream_t st) {
+  static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), true);
+  (void)once;
+  if (g.a_rpg <= 0) { g.a_rpg = g.M > 0 ? g.M : 1; g.a_gstride = 0; }
+  launch_gemm<T, AM, EPI>(g, st);
+}
+
+template <typename T> struct Ctx {
+  const bsg_model* m;
+  hipStream_t st;
+  char* ws;
+  Plan plan;
+  int B;
+  template <typename U = void> U* at(const char* name, int layer = -1) const {
+    const Region* r = plan.find(name, layer);
+    return r ? (U*)(ws + r->off) : nullptr;
+  }
+};
+
+template <typename T> static void ln_fwd(const Ctx<T>& c, const float* x, const void* g, const void* b, T* y, long ldy, int rows) {
+  hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, c.st, x, (const float*)g, (const float*)b, y,
+                     ldy, rows, c.m->c.hidden_size, c.m->c.layer_norm_eps);
+}
+template <typename T>
+static void ln_bwd(const Ctx<T>& c, const T* dy, long lddy, const float* x, const void* g, const float* dx_in, float* dx_out,
+                   T* dx_t, int rows) {
+  hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, c.st, dy, lddy, x, (const float*)g, dx_in, 1.0f,
+                     dx_out, dx_t, rows, c.m->c.hidden_size, c.m->c.layer_norm_eps);
+}
+
+template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int B, const float* pix, const float* prm,
+                                              const float* pmask, int emb, float* pred, void* ws, int train) {
+  Ctx<T> c{m, st, (char*)ws, make_plan(m, B, train), B};
+  const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
+  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps;
+  const float scale = 0.125f;  // head_dim^-0.5, head_dim == 64
+  T* patch_a = c.template at<T>("patch_a");
+  T* ln_out = c.template at<T>("ln_out");
+  T* h_act = c.template at<T>("h_act");
+  T* vt = c.template at<T>("vt");
+  float* relh = c.template at<float>("relh");
+  float* relw = c.template at<float>("relw");
+  T* taps = c.template at<T>("taps");
+  T* feat = c.template at<T>("feat");
+
+  {
+    const long total = (long)2 * B * N * 48;
+    hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)std::min<long>((total + 255) / 256, 65535 * 16)), dim3(256), 0, st,
+                       prm, pix, pmask, patch_a, B, hp, wp);
+    CHECK_LAUNCH();
+  }
+  float* pool[3] = {c.template at<float>("x_a"), c.template at<float>("x_b"), c.template at<float>("x_c")};
+  float* x_cur = train ? c.template at<float>("x_in", 0) : pool[0];
+  {
+    GemmArgs g{};
+    g.A = patch_a; g.W = m->gw(0); g.M = 2 * B * N; g.N = D; g.K = 768; g.lda = 768;
+    g.tokens = N; g.batch = B; g.out = x_cur; g.ldo = D; g.aux = m->gw(emb == 0 ? 2 : 3); g.ldaux = D;
+    gemm<T, A_PLAIN, EPI_EMBED>(g, st);
+    CHECK_LAUNCH();
+  }
+  for (int l = 0; l < L; ++l) {
+    const int S = m->streams(l, B), rows = S * N;
+    float* x_mid = train ? c.template at<float>("x_mid", l) : (x_cur == pool[1] ? pool[2] : pool[1]);
+    T* qkv = c.template at<T>("qkv", train ? l : -1);
+    T* attn_o = c.template at<T>("attn_o", train ? l : -1);
+    float* lse2 = c.template at<float>("lse2", train ? l : -1);
+    T* h_pre = train ? c.template at<T>("h_pre", l) : nullptr;
+    ln_fwd<T>(c, x_cur, m->lw(l, 0), m->lw(l, 1), ln_out, D, rows);
+    CHECK_LAUNCH();
+    {
+      GemmArgs g{};
+      g.A = ln_out; g.W = m->lw(l, 2); g.M = rows; g.N = 3 * D; g.K = D; g.lda = D;
+      g.bias = (const float*)m->lw(l, 4); g.out = qkv; g.ldo = 3 * D;
+      gemm<T, A_PLAIN, EPI_BIAS>(g, st);
+      CHECK_LAUNCH();
+    }
+    {
+      const int lds = (64 + 2 * hp - 1 + 2 * wp - 1) * 65 * 4;
+      static bool once = (allow_lds(relpos_fwd_kernel<T>, 160 * 1024), true);
+      (void)once;
+      hipLaunchKernelGGL((relpos_fwd_kernel<T>), dim3((N + 63) / 64, nh, S), dim3(256), lds, st, qkv, (long)3 * D,
+                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), relh, relw, (float*)nullptr,
+                         (float*)nullptr, N, hp, wp, nh, 1.0f / scale);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
+                         wp, nh);
+      CHECK_LAUNCH();
+      AttnArgs a{};
+      a.q = qkv; a.k = qkv + D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o; a.ldo = D;
+      a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
+      const int albytes = 4 * AttnK<T>::TILE;
+      static bool once2 = (allow_lds(attn_fwd_kernel<T>, 4 * AttnK<T>::TILE), true);
+      (void)once2;
+      hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3((N + 127) / 128, nh, S), dim3(256), albytes, st, a);
+      CHECK_LAUNCH();
+    }
+    {
+      GemmArgs g{};
+      g.A = attn_o; g.W = m->lw(l, 5); g.M = rows; g.N = D; g.K = D; g.lda = D;
+      g.bias = (const float*)m->lw(l, 7); g.out = x_mid; g.ldo = D; g.aux = x_cur; g.ldaux = D;
+      gemm<T, A_PLAIN, EPI_BIAS_RESID>(g, st);
+      CHECK_LAUNCH();
+    }
+    ln_fwd<T>(c, x_mid, m->lw(l, 8), m->lw(l, 9), ln_out, D, rows);
+    CHECK_LAUNCH();
+    {
+      GemmArgs g{};
+      g.A = ln_out; g.W = m->lw(l, 10); g.M = rows; g.N = mlp; g.K = D; g.lda = D;
+      g.bias = (const float*)m->lw(l, 12); g.out = h_act; g.out2 = h_pre; g.ldo = mlp;
+      gemm<T, A_PLAIN, EPI_BIAS_GELU>(g, st);
+      CHECK_LAUNCH();
+    }
+    float* x_out;
+    if (train) x_out = l == m->c.merge_index ? c.template at<float>("x_tmp") : c.template at<float>("x_in", l + 1);
+    else {
+      x_out = pool[0];
+      for (int i = 0; i < 3; ++i) if (pool[i] != x_cur && pool[i] != x_mid) x_out = pool[i];
+    }
+    {
+      GemmArgs g{};
+      g.A = h_act; g.W = m->lw(l, 13); g.M = rows; g.N = D; g.K = mlp; g.lda = mlp;
+      g.bias = (const float*)m->lw(l, 15); g.out = x_out; g.ldo = D; g.aux = x_mid; g.ldaux = D;
+      gemm<T, A_PLAIN, EPI_BIAS_RESID>(g, st);
+      CHECK_LAUNCH();
+    }
+    if (l == m->c.merge_index) {
+      float* merged = train ? c.template at<float>("x_in", l + 1) : x_cur;  // x_cur (layer input) is dead by now
+      const long n4 = (long)B * N * D / 4;
+      hipLaunchKernelGGL(merge_halves_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 65535)), dim3(256), 0, st, x_out,
+                         merged, n4);
+      CHECK_LAUNCH();
+      x_cur = merged;
+    } else {
+      x_cur = x_out;
+    }
+    int ti;
+    if (m->is_tap(l, &ti)) {
+      if (l < m->c.merge_index) return fail("tap %d before merge_index %d", l, m->c.merge_index);
+      ln_fwd<T>(c, x_cur, m->gw(4), m->gw(5), taps + (long)ti * D, (long)nt * D, B * N);
+      CHECK_LAUNCH();
+    }
+  }
+  {
+    GemmArgs g{};
+    g.A = taps; g.W = m->gw(6); g.M = B * N; g.N = 256 * 64; g.K = nt * D; g.lda = (long)nt * D;
+    g.bias = (const float*)m->gw(8); g.out = feat; g.tokens = N; g.wp = wp; g.himg = m->c.canvas_h; g.wimg = m->c.canvas_w;
+    gemm<T, A_PLAIN, EPI_FEAT>(g, st);
+    CHECK_LAUNCH();
+  }
+  {
+    ConvArgs a{};
+    a.in = feat; a.w = m->gw(9); a.bias = (const float*)m->gw(11); a.out = train ? c.template at<T>("conv_out") : nullptr;
+    a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
+    a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
+    const int lds = 340 * 64 * sizeof(T);
+    static bool once = (allow_lds(conv3x3_kernel<T, CONV_FWD_FUSED>, 340 * 64 * sizeof(T)), true);
+    (void)once;
+    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_FWD_FUSED>), dim3(a.W / 32, a.H / 8, B), dim3(256), lds, st, a);
+    CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int B, const float* dpred, float* gprompt, void* ws) {
+  Ctx<T> c{m, st, (char*)ws, make_plan(m, B, 1), B};
+  const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
+  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, H = m->c.canvas_h, W = m->c.canvas_w;
+  const int rows = B * N;
+  const float scale = 0.125f;
+  constexpr bool kF32 = sizeof(T) == 4;
+  T* dconv = c.template at<T>("feat");
+  T* dfeat = c.template at<T>("feat2");
+  T* dtaps = c.template at<T>("dtaps");
+  float* dx = c.template at<float>("dx");
+  T* dx_t = kF32 ? (T*)dx : c.template at<T>("dx_t");
+  T* dx_t_out = kF32 ? nullptr : dx_t;  // f32 mode: the fp32 stream itself feeds the dgrad GEMMs
+  T* dh = c.template at<T>("dh");
+  T* dn_a = c.template at<T>("dn_a");
+  T* dn_b = c.template at<T>("dn_b");
+  T* dqkv = c.template at<T>("dqkv");
+  T* kt = c.template at<T>("kt");
+  T* qt = c.template at<T>("qt");
+  T* dot = c.template at<T>("dot");
+  float* delta = c.template at<float>("delta");
+  float* drelh = c.template at<float>("drelh");
+  float* drelw = c.template at<float>("drelw");
+  float* relh = c.template at<float>("relh");
+  float* relw = c.template at<float>("relw");
+  float* relhT = c.template at<float>("relhT");
+  float* relwT = c.template at<float>("relwT");
+
+  {
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
+                       c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
+                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps);
+    CHECK_LAUNCH();
+    ConvArgs a{};
+    a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
+    const int lds = 340 * 64 * sizeof(T);
+    static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, 340 * 64 * sizeof(T)), true);
+    (void)once;
+    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8, B), dim3(256), lds, st, a);
+    CHECK_LAUNCH();
+    GemmArgs g{};
+    g.A = dfeat; g.W = m->gw(7); g.M = rows; g.N = nt * D; g.K = 256 * 64; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
+    g.out = dtaps; g.ldo = (long)nt * D;
+    gemm<T, A_FEAT, EPI_PLAIN>(g, st);
+    CHECK_LAUNCH();
+  }
+  bool dx_valid = false;
+  for (int l = L - 1; l >= 0; --l) {
+    int ti;
+    if (m->is_tap(l, &ti)) {  // d/dx of the shared tap LayerNorm applied to x_in[l+1]  (HF:475-476)
+      ln_bwd<T>(c, dtaps + (long)ti * D, (long)nt * D, c.template at<float>("x_in", l + 1), m->gw(4), dx_valid ? dx : nullptr, dx,
+                dx_t_out, rows);
+      CHECK_LAUNCH();
+      dx_valid = true;
+    }
+    if (!dx_valid) continue;
+    if (l == m->c.merge_index) {  // x = (img + mask) / 2: the image stream receives half; the mask stream has no leaf
+      const long n4 = (long)rows * D / 4;
+      const unsigned gb = (unsigned)std::min<long>((n4 + 255) / 256, 65535);
+      hipLaunchKernelGGL((cast_rows_kernel<float>), dim3(gb), dim3(256), 0, st, dx, dx, n4, 0.5f);
+      if (!kF32) hipLaunchKernelGGL((cast_rows_kernel<T>), dim3(gb), dim3(256), 0, st, dx, dx_t, n4, 1.0f);
+      CHECK_LAUNCH();
+    }
+    const T* qkv = c.template at<T>("qkv", l);
+    const T* attn_o = c.template at<T>("attn_o", l);
+    {
+      GemmArgs g{};
+      g.A = dx_t; g.W = m->lw(l, 14); g.M = rows; g.N = mlp; g.K = D; g.lda = D; g.out = dh; g.ldo = mlp;
+      g.aux = c.template at<T>("h_pre", l); g.ldaux = mlp;
+      gemm<T, A_PLAIN, EPI_GELU_BWD>(g, st);
+      CHECK_LAUNCH();
+      GemmArgs g2{};
+      g2.A = dh; g2.W = m->lw(l, 11); g2.M = rows; g2.N = D; g2.K = mlp; g2.lda = mlp; g2.out = dn_a; g2.ldo = D;
+      gemm<T, A_PLAIN, EPI_PLAIN>(g2, st);
+      CHECK_LAUNCH();
+    }
+    ln_bwd<T>(c, dn_a, D, c.template at<float>("x_mid", l), m->lw(l, 8), dx, dx, dx_t_out, rows);
+    CHECK_LAUNCH();
+    {
+      GemmArgs g{};
+      g.A = dx_t; g.W = m->lw(l, 6); g.M = rows; g.N = D; g.K = D; g.lda = D; g.out = dn_b; g.ldo = D;
+      gemm<T, A_PLAIN, EPI_PLAIN>(g, st);
+      CHECK_LAUNCH();
+    }
+    {  // attention backward on the B image streams
+      hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)dn_b, attn_o, (long)D, delta,
+                         B, N, hp, wp, nh);
+      CHECK_LAUNCH();
+      const int lds = (64 + 2 * hp - 1 + 2 * wp - 1) * 65 * 4;
+      hipLaunchKernelGGL((relpos_fwd_kernel<T>), dim3((N + 63) / 64, nh, B), dim3(256), lds, st, qkv, (long)3 * D,
+                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), relh, relw, relhT, relwT, N, hp, wp, nh,
+                         1.0f / scale);
+      CHECK_LAUNCH();
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
+                         nh);
+      CHECK_LAUNCH();
+      AttnArgs a{};
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.relh = relh;
+      a.relw = relw; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.dq = dqkv; a.drelh = drelh; a.drelw = drelw;
+      a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
+      static bool once = (allow_lds(attn_bwd_dq_kernel<T>, 6 * AttnK<T>::TILE), true);
+      (void)once;
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3((N + 127) / 128, nh, B), dim3(256), 6 * AttnK<T>::TILE, st, a);
+      CHECK_LAUNCH();
+      const int lds2 = (2 * hp - 1 + 2 * wp - 1) * 64 * 4;
+      static bool once3 = (allow_lds(relpos_bwd_kernel<T>, 160 * 1024), true);
+      (void)once3;
+      hipLaunchKernelGGL((relpos_bwd_kernel<T>), dim3((N + 63) / 64, nh, B), dim3(256), lds2, st, dqkv, (long)3 * D,
+                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), (const float*)drelh, (const float*)drelw, N,
+                         hp, wp, nh);
+      CHECK_LAUNCH();
+      AttnBwdKvArgs k{};
+      k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
+      k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
+      k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
+      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T>, 8 * AttnK<T>::TILE), true);
+      (void)once2;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp / 2 + 3) / 4, nh, B), dim3(256), 8 * AttnK<T>::TILE, st, k);
+      CHECK_LAUNCH();
+    }
+    {
+      GemmArgs g{};
+      g.A = dqkv; g.W = m->lw(l, 3); g.M = rows; g.N = D; g.K = 3 * D; g.lda = 3 * D; g.out = dn_a; g.ldo = D;
+      gemm<T, A_PLAIN, EPI_PLAIN>(g, st);
+      CHECK_LAUNCH();
+    }
+    ln_bwd<T>(c, dn_a, D, c.template at<float>("x_in", l), m->lw(l, 0), dx, dx, dx_t_out, rows);
+    CHECK_LAUNCH();
+  }
+  if (!dx_valid) return fail("no tap reaches the loss: gradient is identically zero");
+  {  // patch-embed dgrad over the prompt (top) half of the image canvas, un-patchified straight into the output
+    GemmArgs g{};
+    g.A = dx_t; g.W = m->gw(1); g.M = B * (N / 2); g.N = 768; g.K = D; g.lda = D; g.a_rpg = N / 2; g.a_gstride = N;
+    g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W; g.out = gprompt;
+    gemm<T, A_PLAIN, EPI_UNPATCH>(g, st);
+    CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* bsg_last_error(void) { return g_err.c_str(); }
+const char* bsg_build_info(void) { return "beach_seg_amd hip kernels, gfx950, built " __DATE__ " " __TIME__; }
+
+int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights, bsg_model** out) {
+  if (!cfg || !weights || !out) return fail("bsg_create: null argument");
+  const bsg_config& c = *cfg;
+  if (c.dtype != BSG_DTYPE_F32 && c.dtype != BSG_DTYPE_BF16) return fail("dtype must be 0 (f32) or 1 (bf16)");
+  if (c.patch_size != 16) return fail("patch_size must be 16");
+  if (c.decoder_hidden != 64) return fail("decoder_hidden must be 64");
+  if (c.num_heads <= 0 || c.hidden_size != c.num_heads * 64) return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
+  if (c.hidden_size % 64 || c.mlp_dim % 64 || c.hidden_size > 2048) return fail("hidden_size / mlp_dim must be multiples of 64, hidden <= 2048");
+  if (c.canvas_h % 32 || c.canvas_w % 32) return fail("canvas must be a multiple of 32 pixels in both axes");
+  const int hp = c.canvas_h / 16, wp = c.canvas_w / 16;
+  if (wp > 32) return fail("token-grid width %d > 32 not supported", wp);
+  if (c.num_taps < 1 || c.num_taps > BSG_MAX_TAPS) return fail("num_taps out of range");
+  for (int i = 0; i < c.num_taps; ++i)
+    if (c.taps[i] < c.merge_index || c.taps[i] >= c.num_layers) return fail("tap index %d out of range", c.taps[i]);
+  if (c.merge_index < 0 || c.merge_index >= c.num_layers) return fail("merge_index out of range");
+  const int need = BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * c.num_layers;
+  if (n_weights != need) return fail("weight table has %d entries, expected %d", n_weights, need);
+  for (int i = 0; i < need; ++i) if (!weights[i]) return fail("weight table entry %d is null", i);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device: the MI355X kernels cannot run here");
+  bsg_model* m = new bsg_model();
+  m->c = c;
+  m->w.assign(weights, weights + need);
+  m->hp = hp; m->wp = wp; m->N = hp * wp; m->npad = hp * 32; m->es = c.dtype == BSG_DTYPE_F32 ? 4 : 2;
+  *out = m;
+  return 0;
+}
+
+void bsg_destroy(bsg_model* m) { delete m; }
+
+size_t bsg_workspace_bytes(const bsg_model* m, int batch, int train) {
+  if (!m || batch <= 0) return 0;
+  return make_plan(m, batch, train).total;
+}
+
+int bsg_workspace_region(const bsg_model* m, int batch, int train, const char* name, int layer, size_t* offset, size_t* bytes) {
+  if (!m || !name) return fail("null argument");
+  Plan p = make_plan(m, batch, train);
+  const Region* r = p.find(name, layer);
+  if (!r) return fail("no workspace region '%s' layer %d", name, layer);
+  if (offset) *offset = r->off;
+  if (bytes) *bytes = r->bytes;
+  return 0;
+}
+
+int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
+                const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace, size_t workspace_bytes,
+                int save_for_backward) {
+  if (!m || !pixel_values || !prompt_pixel_values || !prompt_masks || !pred_masks || !workspace) return fail("bsg_forward: null argument");
+  if (batch <= 0) return fail("batch must be positive");
+  if (embedding_type != 0 && embedding_type != 1)
+    return fail("Embedding type should be either 'semantic' or 'instance', but got %d", embedding_type);
+  if (workspace_bytes < bsg_workspace_bytes(m, batch, save_for_backward))
+    return fail("workspace too small: %zu < %zu", workspace_bytes, bsg_workspace_bytes(m, batch, save_for_backward));
+  hipStream_t st = (hipStream_t)stream;
+  return m->c.dtype == BSG_DTYPE_F32
+             ? forward_impl<float>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward)
+             : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward);
+}
+
+int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values, void* workspace,
+                 size_t workspace_bytes) {
+  if (!m || !grad_pred || !grad_prompt_pixel_values || !workspace) return fail("bsg_backward: null argument");
+  if (workspace_bytes < bsg_workspace_bytes(m, batch, 1)) return fail("workspace too small for backward");
+  hipStream_t st = (hipStream_t)stream;
+  return m->c.dtype == BSG_DTYPE_F32 ? backward_impl<float>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace)
+                                     : backward_impl<bf16_t>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace);
+}
+
+static const int kLossBlocks = 1024;
+size_t bsg_loss_scratch_bytes(int h, int w) { return (size_t)h * w * 4 + kLossBlocks * 4 + 256; }
+
+int bsg_loss_fwd_bwd(void* stream, int batch, int h, int w, const float* pred, const float* labels, const uint8_t* yesdata,
+                     float beta, int variant, float* loss_out, float* grad_pred, void* scratch, size_t scratch_bytes) {
+  if (!pred || !labels || !yesdata || !loss_out || !scratch) return fail("bsg_loss_fwd_bwd: null argument");
+  if (variant != 0 && variant != 1) return fail("loss variant must be 0 (reference) or 1 (per_sample)");
+  if (scratch_bytes < bsg_loss_scratch_bytes(h, w)) return fail("loss scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long hw = (long)h * w;
+  unsigned long long* total = (unsigned long long*)scratch;
+  float* partial = (float*)((char*)scratch + 256);
+  float* counts = partial + kLossBlocks;
+  if (hipMemsetAsync(total, 0, 8, st) != hipSuccess) return fail("memset failed");
+  hipLaunchKernelGGL(loss_prep_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, st, yesdata, counts, total, batch, hw);
+  hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(kLossBlocks), dim3(256), 0, st, pred, labels, yesdata, (const float*)counts,
+                     (const unsigned long long*)total, grad_pred, partial, batch, h, w, beta, variant);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, kLossBlocks,
+                     (const unsigned long long*)total, loss_out);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_decode_argmin(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette_norm,
+                      int64_t* out_i64, uint8_t* out_u8) {
+  if (!pred || !palette_norm || (!out_i64 && !out_u8)) return fail("bsg_decode_argmin: null argument");
+  const long n = (long)batch * h * w;
+  hipLaunchKernelGGL(decode_argmin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
+                     palette_norm, (long long*)out_i64, out_u8, batch, h, w, K);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_prompt_gather(void* stream, int batch, int h, int w, const float* params, const int32_t* idx, const float mean[3],
+                      const float std[3], float* out) {
+  if (!params || !idx || !out) return fail("bsg_prompt_gather: null argument");
+  const long hw = (long)h * w, n = (long)batch * 3 * hw;
+  hipLaunchKernelGGL(prompt_gather_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0,
+                     (hipStream_t)stream, params, out, (const int*)idx, batch, 3 * hw, hw, mean[0], mean[1], mean[2], std[0],
+                     std[1], std[2]);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_prompt_grad_scatter(void* stream, int batch, int h, int w, const float* grad_pixels, const int32_t* idx,
+                            const float std[3], float* grad_params) {
+  if (!grad_pixels || !idx || !grad_params) return fail("bsg_prompt_grad_scatter: null argument");
+  const long hw = (long)h * w, n = (long)batch * 3 * hw;
+  hipLaunchKernelGGL(prompt_grad_scatter_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0,
+                     (hipStream_t)stream, grad_pixels, grad_params, (const int*)idx, batch, 3 * hw, hw, 1.f / std[0],
+                     1.f / std[1], 1.f / std[2]);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, const float* grads, float* exp_avg,
+                   float* exp_avg_sq, const int32_t* active, const float* step_sizes, const float* bc2_sqrts, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !active || !step_sizes || !bc2_sqrts) return fail("bsg_adamw_step: null argument");
+  if (n_active <= 0) return 0;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((row_elems + 255) / 256, 4096), n_active), dim3(256), 0,
+                     (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (const int*)active, step_sizes, bc2_sqrts,
+                     row_elems, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int win, int crop, const int32_t* crops,
+                   uint8_t* counter, int mh, int mw, int K) {
+  if (!masks || !crops || !counter) return fail("bsg_vote_paste: null argument");
+  if (n_crops <= 0) return 0;
+  hipLaunchKernelGGL(vote_paste_kernel, dim3((crop * crop + 255) / 256, n_crops), dim3(256), 0, (hipStream_t)stream, masks,
+                     counter, (const int*)crops, n_crops, hin, win, crop, mh, mw, K);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out) {
+  if (!counter || !out) return fail("bsg_vote_argmax: null argument");
+  hipLaunchKernelGGL(vote_argmax_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, counter,
+                     out, n_pixels, K);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

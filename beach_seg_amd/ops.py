@@ -1,0 +1,145 @@
+"""Torch-facing wrappers of the wrapper-math entry points of the C ABI: the reference's loss
+(`/root/reference/src/model.py:40-64`), palette arg-min decode (`src/model.py:155-175`), prompt gather /
+gradient scatter (`src/model.py:177-213`), AdamW (`src/model.py:398`) and predict-loop voting
+(`src/predict.py:100, 120-159, 259-260`).  Tensors must live on the GPU; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+IMAGE_MEAN = (0.485, 0.456, 0.406)  # SegGptImageProcessor defaults, consumed at src/data.py:192-193
+IMAGE_STD = (0.229, 0.224, 0.225)
+VARIANTS = {"reference": 0, "per_sample": 1}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise N.NativeError("beach_seg_amd.ops run on the MI355X only: tensor is on the CPU")
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, labels, yes, beta, variant):
+        lib = N.load()
+        B, _, H2, W = pred.shape
+        h = H2 // 2
+        pred_c = pred.detach().float().contiguous()
+        labels_c = labels.detach().float().contiguous()
+        yes_c = yes.reshape(B, h, W).to(torch.uint8).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        need = pred.requires_grad
+        grad = torch.empty_like(pred_c) if need else None
+        scratch = torch.empty(lib.bsg_loss_scratch_bytes(h, W), dtype=torch.uint8, device=pred.device)
+        with torch.cuda.device(pred.device):
+            N.check(lib.bsg_loss_fwd_bwd(_stream(), B, h, W, _ptr(pred_c), _ptr(labels_c), _ptr(yes_c), float(beta),
+                                         VARIANTS[variant], _ptr(loss), _ptr(grad), _ptr(scratch), scratch.numel()))
+        ctx.grad = grad
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None, None, None
+
+
+def seggpt_loss(pred, labels, yesdata, beta: float, variant: str = "reference") -> torch.Tensor:
+    """`SegGptLoss.forward` (`src/model.py:45-64`).  pred (B,3,2H,W), labels (B,3,H,W), yesdata bool (B,1,H,W).
+    `variant="reference"` keeps the `unsqueeze(1)` batch broadcast of `:61`."""
+    _need_gpu(pred, labels, yesdata)
+    if variant not in VARIANTS:
+        raise ValueError(f"variant must be one of {list(VARIANTS)}")
+    return _LossFn.apply(pred, labels, yesdata, beta, variant)
+
+
+def decode_argmin(pred: torch.Tensor, palette_norm: torch.Tensor, out_dtype=torch.int64) -> torch.Tensor:
+    """`process_pred_masks` (`src/model.py:155-175`) -> (B,H,W) int64 (reference dtype) or uint8."""
+    _need_gpu(pred, palette_norm)
+    lib = N.load()
+    B, _, H2, W = pred.shape
+    h, K = H2 // 2, palette_norm.shape[1]
+    pred_c = pred.detach().float().contiguous()
+    pal = palette_norm.detach().float().contiguous()
+    out = torch.empty((B, h, W), dtype=out_dtype, device=pred.device)
+    with torch.cuda.device(pred.device):
+        N.check(lib.bsg_decode_argmin(_stream(), B, h, W, K, _ptr(pred_c), _ptr(pal),
+                                      _ptr(out) if out_dtype == torch.int64 else None,
+                                      _ptr(out) if out_dtype == torch.uint8 else None))
+    return out
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def prompt_gather(params: torch.Tensor, idx: torch.Tensor, mean=IMAGE_MEAN, std=IMAGE_STD) -> torch.Tensor:
+    """stack(params[idx]) then Normalize: (P,3,h,w) f32, idx (B,) -> (B,3,h,w) f32."""
+    _need_gpu(params, idx)
+    lib = N.load()
+    B, (_, _, h, w) = idx.numel(), params.shape
+    out = torch.empty((B, 3, h, w), dtype=torch.float32, device=params.device)
+    idx32 = idx.to(torch.int32).contiguous()
+    with torch.cuda.device(params.device):
+        N.check(lib.bsg_prompt_gather(_stream(), B, h, w, _ptr(params), _ptr(idx32), _f3(mean), _f3(std), _ptr(out)))
+    return out
+
+
+def prompt_grad_scatter(grad_pixels: torch.Tensor, idx: torch.Tensor, grad_params: torch.Tensor, std=IMAGE_STD) -> None:
+    """grad_params[idx[b]] += grad_pixels[b] / std  (duplicates accumulate, as autograd through stack does)."""
+    _need_gpu(grad_pixels, idx, grad_params)
+    lib = N.load()
+    B, _, h, w = grad_pixels.shape
+    idx32 = idx.to(torch.int32).contiguous()
+    with torch.cuda.device(grad_params.device):
+        N.check(lib.bsg_prompt_grad_scatter(_stream(), B, h, w, _ptr(grad_pixels.contiguous()), _ptr(idx32), _f3(std),
+                                            _ptr(grad_params)))
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, active: torch.Tensor, steps: list[int], lr: float,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+    """torch.optim.AdamW step on rows `active` of the flat (P, n) buffers; `steps[a]` = that row's step count
+    after this update.  Bias corrections are formed on the host in double, as torch does."""
+    _need_gpu(params, grads, exp_avg, exp_avg_sq, active)
+    lib = N.load()
+    n_active = active.numel()
+    ss = torch.tensor([lr / (1.0 - betas[0] ** t) for t in steps], dtype=torch.float32, device=params.device)
+    b2 = torch.tensor([(1.0 - betas[1] ** t) ** 0.5 for t in steps], dtype=torch.float32, device=params.device)
+    act = active.to(torch.int32).contiguous()
+    row = params[0].numel()
+    with torch.cuda.device(params.device):
+        N.check(lib.bsg_adamw_step(_stream(), n_active, row, _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                   _ptr(act), _ptr(ss), _ptr(b2), lr, betas[0], betas[1], eps, weight_decay, grad_scale))
+
+
+def vote_paste(counter: torch.Tensor, masks: torch.Tensor, crops: torch.Tensor, crop_size: int) -> None:
+    """`cv2.resize(INTER_NEAREST)` + `np.eye(K)[pred]` + `Accumulator.update` for a set of NON-overlapping crops.
+    counter u8 (mh,mw,K); masks u8 (n,hin,win); crops i32 (n,4) = (xmin,ymin,xmax,ymax)."""
+    _need_gpu(counter, masks, crops)
+    lib = N.load()
+    n, hin, win = masks.shape
+    mh, mw, K = counter.shape
+    with torch.cuda.device(counter.device):
+        N.check(lib.bsg_vote_paste(_stream(), n, _ptr(masks.contiguous()), hin, win, crop_size,
+                                   _ptr(crops.to(torch.int32).contiguous()), _ptr(counter), mh, mw, K))
+
+
+def vote_argmax(counter: torch.Tensor) -> torch.Tensor:
+    """`np.argmax(counter, axis=2)` (`src/predict.py:100`) -> u8 (mh,mw)."""
+    _need_gpu(counter)
+    lib = N.load()
+    mh, mw, K = counter.shape
+    out = torch.empty((mh, mw), dtype=torch.uint8, device=counter.device)
+    with torch.cuda.device(counter.device):
+        N.check(lib.bsg_vote_argmax(_stream(), _ptr(counter), mh * mw, K, _ptr(out)))
+    return out

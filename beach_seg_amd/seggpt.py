@@ -1,0 +1,239 @@
+"""`SegGptNative`: drop-in for the object the reference gets from `load_model`
+(`/root/reference/src/util/ml_util.py:7-13`, a frozen `transformers.SegGptForImageSegmentation`) at its call
+sites `self.model(pixel_values=, prompt_pixel_values=, prompt_masks=, labels=, embedding_type=)`
+(`src/model.py:139-144, 245-251, 282-288`).  Same keyword signature (`HF:modeling_seggpt.py:831-844`), same
+output attribute (`out.pred_masks`, f32 (B,3,2H,W), on the autograd graph with a gradient path to
+`prompt_pixel_values`), same `ValueError`s.  All arithmetic runs in the hand-written HIP kernels behind the
+C ABI (`include/beach_seg_amd.h`); torch only owns device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+from .weights import SegGptGeometry, state_dict_shapes
+
+
+@dataclass
+class SegGptImageSegmentationOutput:
+    """Fields of `HF:modeling_seggpt.py:63-85`; the reference reads only `pred_masks`."""
+    loss: Optional[torch.Tensor] = None
+    pred_masks: Optional[torch.Tensor] = None
+    hidden_states: None = None
+    attentions: None = None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def token_tables(sd: dict, g: SegGptGeometry) -> tuple[torch.Tensor, torch.Tensor]:
+    """Constant folding of `SegGptEmbeddings.forward` (`HF:163-206`) under the default `bool_masked_pos`
+    (`HF:902-909`): per (stream kind, token) the sum of conv bias (or mask_token where the mask stream is
+    masked), segment token, bicubic-resized position embedding (`HF:145-161`) and type token.
+    Returns (instance, semantic) tables, each f32 (2, N, D), computed on the CPU in fp32."""
+    e = "model.embeddings."
+    hp, wp = g.grid
+    D = g.hidden_size
+    cpu = {k: v.detach().float().cpu() for k, v in sd.items() if k.startswith(e)}
+    pe = cpu[e + "position_embeddings"][:, 1:]
+    n = int(round(pe.shape[1] ** 0.5))
+    if n != hp or n != wp:
+        pe = F.interpolate(pe.reshape(1, n, n, -1).permute(0, 3, 1, 2), size=(hp, wp), mode="bicubic",
+                           align_corners=False).permute(0, 2, 3, 1)
+    pos = pe.reshape(hp * wp, D)
+    bias = cpu[e + "patch_embeddings.projection.bias"].reshape(1, D)
+    masked = torch.arange(hp * wp) >= (hp * wp) // 2
+    out = []
+    for ty in ("type_token_instance", "type_token_semantic"):
+        t = cpu[e + ty].reshape(1, D)
+        img = bias + cpu[e + "segment_token_input"].reshape(1, D) + pos + t
+        first = torch.where(masked[:, None], cpu[e + "mask_token"].reshape(1, D).expand(hp * wp, D),
+                            bias.expand(hp * wp, D))
+        msk = first + cpu[e + "segment_token_prompt"].reshape(1, D) + pos + t
+        out.append(torch.stack([img, msk]).contiguous())
+    return out[0], out[1]
+
+
+def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) -> list[torch.Tensor]:
+    """Device tensors in the slot order documented in `include/beach_seg_amd.h`."""
+    missing = [k for k in state_dict_shapes(g) if k not in sd]
+    if missing:
+        raise KeyError(f"state dict lacks {missing[:3]}... ({len(missing)} keys)")
+    for k, shp in state_dict_shapes(g).items():
+        if tuple(sd[k].shape) != shp:
+            raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shp}")
+    D = g.hidden_size
+
+    def T(x):  # activation dtype
+        return x.detach().to(device=device, dtype=dtype).contiguous()
+
+    def f32(x):
+        return x.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def lin(name):  # (weight [out][in], weight^T [in][out])
+        w = sd[name].detach().to(device=device, dtype=torch.float32)
+        return T(w), T(w.t())
+
+    tab_i, tab_s = token_tables(sd, g)
+    pw = sd["model.embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
+    cw = sd["decoder.decoder_pred.conv.weight"].detach().to(device=device, dtype=torch.float32)  # [co][ci][ky][kx]
+    conv_w = cw.permute(0, 2, 3, 1).reshape(64, 9, 64)  # [co][tap][ci]
+    conv_wT = cw.flip(2, 3).permute(1, 2, 3, 0).reshape(64, 9, 64)  # [ci][tap'][co], taps flipped (dgrad)
+    dw, dwT = lin("decoder.decoder_embed.weight")
+    table = [
+        T(pw), T(pw.t()), f32(tab_i), f32(tab_s),
+        f32(sd["model.encoder.layernorm.weight"]), f32(sd["model.encoder.layernorm.bias"]),
+        dw, dwT, f32(sd["decoder.decoder_embed.bias"]), T(conv_w), T(conv_wT),
+        f32(sd["decoder.decoder_pred.conv.bias"]), f32(sd["decoder.decoder_pred.layernorm.weight"]),
+        f32(sd["decoder.decoder_pred.layernorm.bias"]),
+        f32(sd["decoder.decoder_pred.head.weight"].reshape(3, 64)), f32(sd["decoder.decoder_pred.head.bias"]),
+    ]
+    assert len(table) == N.BSG_GLOBAL_WEIGHTS
+    for i in range(g.num_hidden_layers):
+        l = f"model.encoder.layers.{i}."
+        qw, qwT = lin(l + "attention.qkv.weight")
+        ow, owT = lin(l + "attention.proj.weight")
+        w1, w1T = lin(l + "mlp.lin1.weight")
+        w2, w2T = lin(l + "mlp.lin2.weight")
+        table += [
+            f32(sd[l + "layernorm_before.weight"]), f32(sd[l + "layernorm_before.bias"]),
+            qw, qwT, f32(sd[l + "attention.qkv.bias"]), ow, owT, f32(sd[l + "attention.proj.bias"]),
+            f32(sd[l + "layernorm_after.weight"]), f32(sd[l + "layernorm_after.bias"]),
+            w1, w1T, f32(sd[l + "mlp.lin1.bias"]), w2, w2T, f32(sd[l + "mlp.lin2.bias"]),
+            f32(sd[l + "attention.rel_pos_h"]), f32(sd[l + "attention.rel_pos_w"]),
+        ]
+    return table
+
+
+class _SegGptFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: "SegGptNative", pixel_values, prompt_pixel_values, prompt_masks, emb: int):
+        need_grad = prompt_pixel_values.requires_grad and torch.is_grad_enabled()
+        pred = model._run_forward(pixel_values.detach(), prompt_pixel_values.detach(), prompt_masks.detach(), emb,
+                                  train=need_grad)
+        ctx.model, ctx.batch = model, pixel_values.shape[0]
+        return pred
+
+    @staticmethod
+    def backward(ctx, grad_pred):
+        g = ctx.model._run_backward(grad_pred.contiguous().float(), ctx.batch)
+        return None, None, g, None, None
+
+
+class SegGptNative(torch.nn.Module):
+    """Frozen SegGPT on the HIP kernels.  `dtype`: torch.float32 (parity mode) or torch.bfloat16."""
+
+    def __init__(self, state_dict: dict, geometry: SegGptGeometry, device="cuda:0", dtype=torch.bfloat16):
+        super().__init__()
+        geometry.validate()
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be torch.float32 or torch.bfloat16")
+        self.geometry, self.dtype = geometry, dtype
+        self._device = torch.device(device)
+        self._lib = N.load()
+        self._table = build_weight_table(state_dict, geometry, dtype, self._device)
+        cfg = N.BsgConfig()
+        g = geometry
+        cfg.hidden_size, cfg.num_layers, cfg.num_heads = g.hidden_size, g.num_hidden_layers, g.num_attention_heads
+        cfg.canvas_h, cfg.canvas_w, cfg.patch_size, cfg.mlp_dim = g.image_size[0], g.image_size[1], g.patch_size, g.mlp_dim
+        cfg.decoder_hidden, cfg.merge_index = g.decoder_hidden_size, g.merge_index
+        cfg.num_taps = len(g.intermediate_hidden_state_indices)
+        for i, t in enumerate(g.intermediate_hidden_state_indices):
+            cfg.taps[i] = t
+        cfg.layer_norm_eps = g.layer_norm_eps
+        cfg.dtype = N.BSG_DTYPE_F32 if dtype == torch.float32 else N.BSG_DTYPE_BF16
+        ptrs = (C.c_void_p * len(self._table))(*[t.data_ptr() for t in self._table])
+        h = C.c_void_p()
+        with torch.cuda.device(self._device):
+            N.check(self._lib.bsg_create(C.byref(cfg), ptrs, len(self._table), C.byref(h)))
+        self._h = h
+        self._ws: dict[tuple[int, int], torch.Tensor] = {}
+        self._last_ws: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bsg_destroy(h)
+
+    # ---- surface the reference touches on the HF object
+    @property
+    def device(self) -> torch.device:  # src/model.py:98
+        return self._device
+
+    def eval(self):  # src/util/ml_util.py:11 -- weights are frozen and DropPath is the identity already
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- C ABI calls
+    def workspace(self, batch: int, train: bool) -> torch.Tensor:
+        key = (batch, int(train))
+        if key not in self._ws:
+            n = self._lib.bsg_workspace_bytes(self._h, batch, int(train))
+            self._ws[key] = torch.zeros(n, dtype=torch.uint8, device=self._device)  # ABI: zero-initialised
+        return self._ws[key]
+
+    def workspace_region(self, batch: int, train: bool, name: str, layer: int = -1) -> torch.Tensor:
+        """uint8 view of a named region of the most recent workspace of that shape (test / debugging aid)."""
+        off, nb = C.c_size_t(), C.c_size_t()
+        N.check(self._lib.bsg_workspace_region(self._h, batch, int(train), name.encode(), layer, C.byref(off), C.byref(nb)))
+        return self.workspace(batch, train)[off.value: off.value + nb.value]
+
+    def _run_forward(self, pix, prm, pmask, emb: int, train: bool) -> torch.Tensor:
+        B = pix.shape[0]
+        H, W = self.geometry.image_size
+        pix, prm, pmask = (t.to(self._device, torch.float32).contiguous() for t in (pix, prm, pmask))
+        pred = torch.empty((B, 3, H, W), dtype=torch.float32, device=self._device)
+        ws = self.workspace(B, train)
+        with torch.cuda.device(self._device):
+            N.check(self._lib.bsg_forward(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb, _ptr(pred),
+                                          _ptr(ws), ws.numel(), int(train)))
+        self._last_ws = ws if train else None
+        return pred
+
+    def _run_backward(self, grad_pred: torch.Tensor, B: int) -> torch.Tensor:
+        if self._last_ws is None:
+            raise RuntimeError("backward without a forward that saved activations")
+        H, W = self.geometry.image_size
+        g = torch.empty((B, 3, H // 2, W), dtype=torch.float32, device=self._device)
+        ws = self._last_ws
+        with torch.cuda.device(self._device):
+            N.check(self._lib.bsg_backward(self._h, _stream(), B, _ptr(grad_pred), _ptr(g), _ptr(ws), ws.numel()))
+        return g
+
+    def forward(self, pixel_values, prompt_pixel_values, prompt_masks, bool_masked_pos=None, feature_ensemble=None,
+                embedding_type=None, labels=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, **kwargs) -> SegGptImageSegmentationOutput:
+        g = self.geometry
+        if bool_masked_pos is not None or feature_ensemble:
+            raise NotImplementedError("only the reference's call pattern is built: default bool_masked_pos, "
+                                      "feature_ensemble=False (src/model.py:139-144, 245-251, 282-288)")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / hidden states are never materialised by the fused kernels")
+        if pixel_values.shape[1] != g.num_channels:  # HF:112-115
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in "
+                             "the configuration.")
+        Hh, W = g.image_size[0] // 2, g.image_size[1]
+        for t in (pixel_values, prompt_pixel_values, prompt_masks) + ((labels,) if labels is not None else ()):
+            if tuple(t.shape[2:]) != (Hh, W) or t.shape[0] != pixel_values.shape[0] or t.shape[1] != 3:
+                raise ValueError(f"Input image size ({2 * t.shape[2]}*{t.shape[3]}) doesn't match model "
+                                 f"({g.image_size[0]}*{g.image_size[1]}).")  # HF:116-119
+        embedding_type = "instance" if embedding_type is None else embedding_type
+        if embedding_type not in ("instance", "semantic"):  # HF:199
+            raise ValueError(f"Embedding type should be either 'semantic' or 'instance', but got {embedding_type}")
+        emb = 0 if embedding_type == "instance" else 1
+        pred = _SegGptFn.apply(self, pixel_values, prompt_pixel_values, prompt_masks, emb)
+        # `labels` never reach the network under the default mask (HF:706-715); HF's own `loss` output is
+        # unused by the reference (src/model.py:292), so it is not computed here.
+        return SegGptImageSegmentationOutput(loss=None, pred_masks=pred)

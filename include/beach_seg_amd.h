@@ -1,0 +1,120 @@
+/* C ABI of the MI355X-native SegGPT hot path of kyle-dorman/beach_seg.
+ *
+ * This is the drop-in boundary for the keyword call the reference makes on the object returned by
+ * `load_model` (src/util/ml_util.py:7-13):
+ *     self.model(pixel_values=, prompt_pixel_values=, prompt_masks=, labels=, embedding_type="instance")
+ * at src/model.py:139-144 (infer), :245-251 (train), :282-288 (val); the callee's signature of record is
+ * transformers/models/seggpt/modeling_seggpt.py:831-844 ("HF:" below).  The reference is pure Python, so the
+ * "FFI for this path" is a ctypes binding (beach_seg_amd/_native.py; INTEGRATION.md shows the stub a
+ * maintainer would add to src/util/ml_util.py).
+ *
+ * Conventions: every entry point returns 0 on success, non-zero on error with a thread-local message from
+ * bsg_last_error().  All device pointers are caller-owned (torch tensors); the library never allocates or
+ * frees device memory.  Everything is enqueued on the caller's HIP stream (`stream` = hipStream_t), there are
+ * no hidden synchronisations, so a call sequence is hipGraph-capturable.  One handle per device; not
+ * thread-safe.  Tensors are contiguous; image tensors are NCHW fp32 exactly as the reference passes them.
+ */
+#ifndef BEACH_SEG_AMD_H
+#define BEACH_SEG_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSG_DTYPE_F32 0  /* parity mode: fp32 storage, exact-f32 MFMA */
+#define BSG_DTYPE_BF16 1 /* throughput mode: bf16 storage / bf16 MFMA, fp32 accumulate + fp32 residual stream */
+#define BSG_MAX_TAPS 8
+#define BSG_GLOBAL_WEIGHTS 16 /* weight-table slots before the per-layer blocks */
+#define BSG_LAYER_WEIGHTS 18  /* slots per encoder layer */
+
+/* Mirror of the SegGptConfig fields the path reads (HF:configuration_seggpt.py:57-75). */
+typedef struct bsg_config {
+  int hidden_size, num_layers, num_heads;
+  int canvas_h, canvas_w; /* image_size: prompt stacked over query on H */
+  int patch_size, mlp_dim, decoder_hidden, merge_index;
+  int num_taps;
+  int taps[BSG_MAX_TAPS]; /* intermediate_hidden_state_indices */
+  float layer_norm_eps;
+  int dtype;
+} bsg_config;
+
+typedef struct bsg_model bsg_model;
+
+/* Weight table (device pointers, caller-owned, must outlive the handle).  "T" = activation dtype of the
+ * config; "wT" = the same Linear weight transposed ([in][out]) for the dgrad GEMMs.
+ * global: 0 patch_w T[D][768]   1 patch_wT T[768][D]   2 tok_table_instance f32[2][N][D]
+ *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*64][taps*D]
+ *         7 dec_wT T[taps*D][256*64]   8 dec_b f32   9 conv_w T[64 co][9][64 ci]   10 conv_wT T[64 ci][9][64 co]
+ *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][64]   15 head_b f32[3]
+ * layer l at 16 + 18*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
+ *         10 fc1_w 11 fc1_wT 12 fc1_b 13 fc2_w 14 fc2_wT 15 fc2_b 16 rel_pos_h f32[2Hp-1][64] 17 rel_pos_w f32
+ * tok_table[kind][t] folds conv bias (or mask_token for masked tokens of the mask stream), segment token,
+ * bicubic-resized position embedding and type token (HF:163-206): pure constants of the checkpoint. */
+int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights, bsg_model** out);
+void bsg_destroy(bsg_model* m);
+
+/* Bytes of caller-provided, ZERO-INITIALISED workspace for a batch of `batch` samples.  `train` != 0 adds the
+ * activations saved for bsg_backward. */
+size_t bsg_workspace_bytes(const bsg_model* m, int batch, int train);
+/* Offset/size of a named workspace region (test & debugging aid); returns non-zero if unknown. */
+int bsg_workspace_region(const bsg_model* m, int batch, int train, const char* name, int layer, size_t* offset,
+                         size_t* bytes);
+
+/* HF:831-951 SegGptForImageSegmentation.forward with the default bool_masked_pos and feature_ensemble=False.
+ * pixel_values / prompt_pixel_values / prompt_masks: f32 (B,3,H/2,W); pred_masks: f32 (B,3,H,W).
+ * `labels` is not a parameter: under the default mask HF never feeds it to the network (HF:706-715) and the
+ * reference ignores `out.loss` (src/model.py:292).  embedding_type: 0 = "instance", 1 = "semantic".
+ * save_for_backward != 0 keeps activations in `workspace` for a following bsg_backward on the same workspace. */
+int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
+                const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace,
+                size_t workspace_bytes, int save_for_backward);
+
+/* dgrad-only backward of the frozen network (what Lightning's loss.backward() executes, src/model.py:233-269):
+ * grad_pred f32 (B,3,H,W) -> grad_prompt_pixel_values f32 (B,3,H/2,W).  Weights receive no gradient
+ * (src/util/ml_util.py:9-10). */
+int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values,
+                 void* workspace, size_t workspace_bytes);
+
+/* SegGptLoss of the reference (src/model.py:40-64).  variant 0 reproduces the unsqueeze(1) batch broadcast
+ * of :61; variant 1 is the per-sample masked mean (identical at B = 1).  pred f32 (B,3,2h,w), labels f32
+ * (B,3,h,w), yesdata u8 (B,h,w).  loss_out: 1 float (device).  grad_pred may be NULL.
+ * scratch: >= bsg_loss_scratch_bytes(h, w) bytes, contents irrelevant. */
+size_t bsg_loss_scratch_bytes(int h, int w);
+int bsg_loss_fwd_bwd(void* stream, int batch, int h, int w, const float* pred, const float* labels,
+                     const uint8_t* yesdata, float beta, int variant, float* loss_out, float* grad_pred,
+                     void* scratch, size_t scratch_bytes);
+
+/* process_pred_masks (src/model.py:155-175): arg-min over K normalised palette colours on the bottom half.
+ * pred f32 (B,3,2h,w), palette_norm f32 (B,K,3); either output may be NULL. */
+int bsg_decode_argmin(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette_norm,
+                      int64_t* out_i64, uint8_t* out_u8);
+
+/* prepare_prompt's gather (src/model.py:197 stack + data.py:224 Normalize) and its backward (scatter-add of
+ * grad / std into the rows of the flat prompt-gradient buffer). params/grads: f32 (P,3,h,w); idx: i32 (B). */
+int bsg_prompt_gather(void* stream, int batch, int h, int w, const float* params, const int32_t* idx,
+                      const float mean[3], const float std[3], float* out);
+int bsg_prompt_grad_scatter(void* stream, int batch, int h, int w, const float* grad_pixels, const int32_t* idx,
+                            const float std[3], float* grad_params);
+
+/* torch.optim.AdamW step (src/model.py:398) on the `n_active` prompt rows listed in `active` (device i32).
+ * step_sizes / bc2_sqrts: device f32 [n_active], lr/(1-beta1^t) and sqrt(1-beta2^t) per active row. */
+int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, const float* grads, float* exp_avg,
+                   float* exp_avg_sq, const int32_t* active, const float* step_sizes, const float* bc2_sqrts,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale);
+
+/* Predict-loop glue (src/predict.py:259-260, 120-159, 100): nearest-resize each (hin,win) u8 class mask to
+ * (crop,crop), one-hot vote into the u8 (mh,mw,K) mosaic counters with clipping; crops i32 (n,4) =
+ * (xmin,ymin,xmax,ymax), must not overlap within one call.  Then arg-max over K. */
+int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int win, int crop,
+                   const int32_t* crops, uint8_t* counter, int mh, int mw, int K);
+int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out);
+
+const char* bsg_last_error(void);
+const char* bsg_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
