@@ -117,8 +117,7 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) 
 
 class _SegGptFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model: "SegGptNative", pixel_values, prompt_pixel_values, prompt_masks, emb: int):
-        need_grad = prompt_pixel_values.requires_grad and torch.is_grad_enabled()
+    def forward(ctx, model: "SegGptNative", pixel_values, prompt_pixel_values, prompt_masks, emb: int, need_grad: bool):
         pred = model._run_forward(pixel_values.detach(), prompt_pixel_values.detach(), prompt_masks.detach(), emb,
                                   train=need_grad)
         ctx.model, ctx.batch = model, pixel_values.shape[0]
@@ -127,7 +126,7 @@ class _SegGptFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_pred):
         g = ctx.model._run_backward(grad_pred.contiguous().float(), ctx.batch)
-        return None, None, g, None, None
+        return None, None, g, None, None, None
 
 
 class SegGptNative(torch.nn.Module):
@@ -161,9 +160,12 @@ class SegGptNative(torch.nn.Module):
         self._last_ws: Optional[torch.Tensor] = None
 
     def __del__(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            self._lib.bsg_destroy(h)
+        try:
+            h = self.__dict__.pop("_h", None)
+            if h:
+                self._lib.bsg_destroy(h)
+        except Exception:  # interpreter shutdown
+            pass
 
     # ---- surface the reference touches on the HF object
     @property
@@ -233,7 +235,8 @@ class SegGptNative(torch.nn.Module):
         if embedding_type not in ("instance", "semantic"):  # HF:199
             raise ValueError(f"Embedding type should be either 'semantic' or 'instance', but got {embedding_type}")
         emb = 0 if embedding_type == "instance" else 1
-        pred = _SegGptFn.apply(self, pixel_values, prompt_pixel_values, prompt_masks, emb)
+        need_grad = torch.is_grad_enabled() and prompt_pixel_values.requires_grad
+        pred = _SegGptFn.apply(self, pixel_values, prompt_pixel_values, prompt_masks, emb, need_grad)
         # `labels` never reach the network under the default mask (HF:706-715); HF's own `loss` output is
         # unused by the reference (src/model.py:292), so it is not computed here.
         return SegGptImageSegmentationOutput(loss=None, pred_masks=pred)
