@@ -97,10 +97,11 @@ __global__ void decode_argmin_kernel(const float* __restrict__ pred, const float
 // parameter's own step count (torch keeps one `step` per Parameter and skips Parameters without a gradient);
 // both are computed on the host in double, as torch does.
 __global__ void adamw_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
-                             float* __restrict__ v, const int* __restrict__ idx,
+                             float* __restrict__ v, const int* __restrict__ idx, const uint8_t* __restrict__ touched,
                              const float* __restrict__ step_sizes, const float* __restrict__ bc2_sqrts, long n,
                              float lr, float beta1, float beta2, float eps, float wd, float grad_scale) {
   const int row = idx[blockIdx.y];
+  if (touched && !touched[row]) return;  // a Parameter without a gradient is skipped entirely, as torch does
   const float step_size = step_sizes[blockIdx.y], bc2s = bc2_sqrts[blockIdx.y];
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long o = (long)row * n + i;

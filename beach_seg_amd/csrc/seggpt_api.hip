@@ -47,10 +47,20 @@ struct Plan {
   }
 };
 
+enum ProfCat { PC_GEMM = 0, PC_ATTN_FWD, PC_ATTN_BWD_DQ, PC_ATTN_BWD_DKV, PC_CONV, PC_ROW, PC_COUNT };
+struct ProfRec { int cat; double flops; hipEvent_t e0, e1; };
+
 struct bsg_model {
   bsg_config c;
   std::vector<const void*> w;
   int hp, wp, N, npad, es;
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+  }
   const void* gw(int i) const { return w[i]; }
   const void* lw(int l, int i) const { return w[BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * l + i]; }
   bool is_tap(int l, int* ti) const {
@@ -116,15 +126,25 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
   return p;
 }
 
+// Optional per-launch timing with HIP events on the caller's stream (bench.py's roofline leg).
+struct ProfScope {
+  bsg_model* m; hipStream_t st; ProfRec r; bool on;
+  ProfScope(const bsg_model* m_, hipStream_t st_, int cat, double flops) : m((bsg_model*)m_), st(st_), on(m_->prof) {
+    if (on) { r.cat = cat; r.flops = flops; r.e0 = m->get_event(); r.e1 = m->get_event(); (void)hipEventRecord(r.e0, st); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(r.e1, st); m->recs.push_back(r); } }
+};
+
 template <typename K> static void allow_lds(K kernel, int bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // ------------------------------------------------------------------------------------------- launch helpers
-template <typename T, int AM, int EPI> static void gemm(GemmArgs g, hipStream_t st) {
+template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, GemmArgs g, hipStream_t st) {
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), true);
   (void)once;
   if (g.a_rpg <= 0) { g.a_rpg = g.M > 0 ? g.M : 1; g.a_gstride = 0; }
+  ProfScope ps(m, st, PC_GEMM, 2.0 * g.M * g.N * g.K);
   launch_gemm<T, AM, EPI>(g, st);
 }
 
@@ -178,7 +198,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     GemmArgs g{};
     g.A = patch_a; g.W = m->gw(0); g.M = 2 * B * N; g.N = D; g.K = 768; g.lda = 768;
     g.tokens = N; g.batch = B; g.out = x_cur; g.ldo = D; g.aux = m->gw(emb == 0 ? 2 : 3); g.ldaux = D;
-    gemm<T, A_PLAIN, EPI_EMBED>(g, st);
+    gemm<T, A_PLAIN, EPI_EMBED>(m, g, st);
     CHECK_LAUNCH();
   }
   for (int l = 0; l < L; ++l) {
@@ -194,7 +214,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = ln_out; g.W = m->lw(l, 2); g.M = rows; g.N = 3 * D; g.K = D; g.lda = D;
       g.bias = (const float*)m->lw(l, 4); g.out = qkv; g.ldo = 3 * D;
-      gemm<T, A_PLAIN, EPI_BIAS>(g, st);
+      gemm<T, A_PLAIN, EPI_BIAS>(m, g, st);
       CHECK_LAUNCH();
     }
     {
@@ -214,6 +234,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       const int albytes = 4 * AttnK<T>::TILE;
       static bool once2 = (allow_lds(attn_fwd_kernel<T>, 4 * AttnK<T>::TILE), true);
       (void)once2;
+      ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
       hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3((N + 127) / 128, nh, S), dim3(256), albytes, st, a);
       CHECK_LAUNCH();
     }
@@ -221,7 +242,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = attn_o; g.W = m->lw(l, 5); g.M = rows; g.N = D; g.K = D; g.lda = D;
       g.bias = (const float*)m->lw(l, 7); g.out = x_mid; g.ldo = D; g.aux = x_cur; g.ldaux = D;
-      gemm<T, A_PLAIN, EPI_BIAS_RESID>(g, st);
+      gemm<T, A_PLAIN, EPI_BIAS_RESID>(m, g, st);
       CHECK_LAUNCH();
     }
     ln_fwd<T>(c, x_mid, m->lw(l, 8), m->lw(l, 9), ln_out, D, rows);
@@ -230,7 +251,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = ln_out; g.W = m->lw(l, 10); g.M = rows; g.N = mlp; g.K = D; g.lda = D;
       g.bias = (const float*)m->lw(l, 12); g.out = h_act; g.out2 = h_pre; g.ldo = mlp;
-      gemm<T, A_PLAIN, EPI_BIAS_GELU>(g, st);
+      gemm<T, A_PLAIN, EPI_BIAS_GELU>(m, g, st);
       CHECK_LAUNCH();
     }
     float* x_out;
@@ -243,7 +264,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = h_act; g.W = m->lw(l, 13); g.M = rows; g.N = D; g.K = mlp; g.lda = mlp;
       g.bias = (const float*)m->lw(l, 15); g.out = x_out; g.ldo = D; g.aux = x_mid; g.ldaux = D;
-      gemm<T, A_PLAIN, EPI_BIAS_RESID>(g, st);
+      gemm<T, A_PLAIN, EPI_BIAS_RESID>(m, g, st);
       CHECK_LAUNCH();
     }
     if (l == m->c.merge_index) {
@@ -267,7 +288,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     GemmArgs g{};
     g.A = taps; g.W = m->gw(6); g.M = B * N; g.N = 256 * 64; g.K = nt * D; g.lda = (long)nt * D;
     g.bias = (const float*)m->gw(8); g.out = feat; g.tokens = N; g.wp = wp; g.himg = m->c.canvas_h; g.wimg = m->c.canvas_w;
-    gemm<T, A_PLAIN, EPI_FEAT>(g, st);
+    gemm<T, A_PLAIN, EPI_FEAT>(m, g, st);
     CHECK_LAUNCH();
   }
   {
@@ -278,6 +299,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     const int lds = 340 * 64 * sizeof(T);
     static bool once = (allow_lds(conv3x3_kernel<T, CONV_FWD_FUSED>, 340 * 64 * sizeof(T)), true);
     (void)once;
+    ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * 64 * 64);
     hipLaunchKernelGGL((conv3x3_kernel<T, CONV_FWD_FUSED>), dim3(a.W / 32, a.H / 8, B), dim3(256), lds, st, a);
     CHECK_LAUNCH();
   }
@@ -323,12 +345,15 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     const int lds = 340 * 64 * sizeof(T);
     static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, 340 * 64 * sizeof(T)), true);
     (void)once;
-    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8, B), dim3(256), lds, st, a);
+    {
+      ProfScope ps(m, st, PC_CONV, 2.0 * B * H * W * 9 * 64 * 64);
+      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8, B), dim3(256), lds, st, a);
+    }
     CHECK_LAUNCH();
     GemmArgs g{};
     g.A = dfeat; g.W = m->gw(7); g.M = rows; g.N = nt * D; g.K = 256 * 64; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
     g.out = dtaps; g.ldo = (long)nt * D;
-    gemm<T, A_FEAT, EPI_PLAIN>(g, st);
+    gemm<T, A_FEAT, EPI_PLAIN>(m, g, st);
     CHECK_LAUNCH();
   }
   bool dx_valid = false;
@@ -354,11 +379,11 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       GemmArgs g{};
       g.A = dx_t; g.W = m->lw(l, 14); g.M = rows; g.N = mlp; g.K = D; g.lda = D; g.out = dh; g.ldo = mlp;
       g.aux = c.template at<T>("h_pre", l); g.ldaux = mlp;
-      gemm<T, A_PLAIN, EPI_GELU_BWD>(g, st);
+      gemm<T, A_PLAIN, EPI_GELU_BWD>(m, g, st);
       CHECK_LAUNCH();
       GemmArgs g2{};
       g2.A = dh; g2.W = m->lw(l, 11); g2.M = rows; g2.N = D; g2.K = mlp; g2.lda = mlp; g2.out = dn_a; g2.ldo = D;
-      gemm<T, A_PLAIN, EPI_PLAIN>(g2, st);
+      gemm<T, A_PLAIN, EPI_PLAIN>(m, g2, st);
       CHECK_LAUNCH();
     }
     ln_bwd<T>(c, dn_a, D, c.template at<float>("x_mid", l), m->lw(l, 8), dx, dx, dx_t_out, rows);
@@ -366,7 +391,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     {
       GemmArgs g{};
       g.A = dx_t; g.W = m->lw(l, 6); g.M = rows; g.N = D; g.K = D; g.lda = D; g.out = dn_b; g.ldo = D;
-      gemm<T, A_PLAIN, EPI_PLAIN>(g, st);
+      gemm<T, A_PLAIN, EPI_PLAIN>(m, g, st);
       CHECK_LAUNCH();
     }
     {  // attention backward on the B image streams
@@ -389,7 +414,10 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static bool once = (allow_lds(attn_bwd_dq_kernel<T>, 6 * AttnK<T>::TILE), true);
       (void)once;
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3((N + 127) / 128, nh, B), dim3(256), 6 * AttnK<T>::TILE, st, a);
+      {
+        ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3((N + 127) / 128, nh, B), dim3(256), 6 * AttnK<T>::TILE, st, a);
+      }
       CHECK_LAUNCH();
       const int lds2 = (2 * hp - 1 + 2 * wp - 1) * 64 * 4;
       static bool once3 = (allow_lds(relpos_bwd_kernel<T>, 160 * 1024), true);
@@ -404,13 +432,16 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
       static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T>, 8 * AttnK<T>::TILE), true);
       (void)once2;
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp / 2 + 3) / 4, nh, B), dim3(256), 8 * AttnK<T>::TILE, st, k);
+      {
+        ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp / 2 + 3) / 4, nh, B), dim3(256), 8 * AttnK<T>::TILE, st, k);
+      }
       CHECK_LAUNCH();
     }
     {
       GemmArgs g{};
       g.A = dqkv; g.W = m->lw(l, 3); g.M = rows; g.N = D; g.K = 3 * D; g.lda = 3 * D; g.out = dn_a; g.ldo = D;
-      gemm<T, A_PLAIN, EPI_PLAIN>(g, st);
+      gemm<T, A_PLAIN, EPI_PLAIN>(m, g, st);
       CHECK_LAUNCH();
     }
     ln_bwd<T>(c, dn_a, D, c.template at<float>("x_in", l), m->lw(l, 0), dx, dx, dx_t_out, rows);
@@ -421,7 +452,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     GemmArgs g{};
     g.A = dx_t; g.W = m->gw(1); g.M = B * (N / 2); g.N = 768; g.K = D; g.lda = D; g.a_rpg = N / 2; g.a_gstride = N;
     g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W; g.out = gprompt;
-    gemm<T, A_PLAIN, EPI_UNPATCH>(g, st);
+    gemm<T, A_PLAIN, EPI_UNPATCH>(m, g, st);
     CHECK_LAUNCH();
   }
   return 0;
@@ -461,7 +492,41 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   return 0;
 }
 
-void bsg_destroy(bsg_model* m) { delete m; }
+void bsg_destroy(bsg_model* m) {
+  if (!m) return;
+  for (auto& r : m->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : m->pool) (void)hipEventDestroy(e);
+  delete m;
+}
+
+int bsg_profile_enable(bsg_model* m, int enable) {
+  if (!m) return fail("null model");
+  m->prof = enable != 0;
+  return 0;
+}
+
+int bsg_profile_read(bsg_model* m, int category, double* total_ms, double* total_flops, long* launches) {
+  if (!m || category < 0 || category >= PC_COUNT) return fail("bsg_profile_read: bad argument");
+  double ms = 0, fl = 0; long n = 0;
+  for (auto& r : m->recs) {
+    if (r.cat != category) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return fail("event sync failed");
+    float t = 0;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return fail("event elapsed failed");
+    ms += t; fl += r.flops; ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return 0;
+}
+
+int bsg_profile_reset(bsg_model* m) {
+  if (!m) return fail("null model");
+  for (auto& r : m->recs) { m->pool.push_back(r.e0); m->pool.push_back(r.e1); }
+  m->recs.clear();
+  return 0;
+}
 
 size_t bsg_workspace_bytes(const bsg_model* m, int batch, int train) {
   if (!m || batch <= 0) return 0;
@@ -558,12 +623,13 @@ int bsg_prompt_grad_scatter(void* stream, int batch, int h, int w, const float* 
 }
 
 int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, const float* grads, float* exp_avg,
-                   float* exp_avg_sq, const int32_t* active, const float* step_sizes, const float* bc2_sqrts, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, float grad_scale) {
+                   float* exp_avg_sq, const int32_t* active, const uint8_t* touched, const float* step_sizes,
+                   const float* bc2_sqrts, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !active || !step_sizes || !bc2_sqrts) return fail("bsg_adamw_step: null argument");
   if (n_active <= 0) return 0;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((row_elems + 255) / 256, 4096), n_active), dim3(256), 0,
-                     (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (const int*)active, step_sizes, bc2_sqrts,
+                     (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (const int*)active, touched, step_sizes, bc2_sqrts,
                      row_elems, lr, beta1, beta2, eps, weight_decay, grad_scale);
   CHECK_LAUNCH();
   return 0;

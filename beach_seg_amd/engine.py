@@ -1,0 +1,68 @@
+"""Fused training step of the hot path, data-parallel over the GPUs of one node.
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  What is trained are the P prompt
+images (`/root/reference/src/model.py:115-130`); the frozen network is replicated.  A step on one rank is
+  gather prompts + Normalize -> SegGPT forward -> SegGptLoss -> dgrad to the prompt pixels -> scatter into the
+  dense (P, 3*h*w) gradient buffer -> [all-reduce] -> AdamW on the touched prompts
+which is `training_step` (`src/model.py:233-269`) + Lightning's `loss.backward()` + `optimizer.step()`
+(`src/model.py:398`), minus the kornia random augmentations.  Everything is enqueued on
+the current stream with no host synchronisation.
+
+The path shards by sample: each rank takes its own B tiles (weak scaling).  The only exchange is ONE sum
+all-reduce per step of the flat prompt-gradient buffer plus its P "touched" flags (P x 602,112 fp32; 154 MB at
+P = 64), the DDP-equivalent of the gradients the reference would reduce; gradients are averaged over ranks as
+DDP does.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .seggpt import SegGptNative
+
+
+class PromptTrainEngine:
+    def __init__(self, model: SegGptNative, prompt_images: torch.Tensor, lr: float = 1e-3, betas=(0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 1e-2, loss_beta: float = 0.01,
+                 loss_variant: str = "reference", process_group=None):
+        """prompt_images: f32 (P,3,h,w) in [0,1] (the `nn.Parameter`s of `src/model.py:121-126`)."""
+        self.model = model
+        dev = model.device
+        self.params = prompt_images.detach().to(dev, torch.float32).contiguous().clone()
+        P = self.params.shape[0]
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.steps = torch.zeros(P, dtype=torch.int64, device=dev)  # one `step` per Parameter, as torch.optim
+        self.rows = torch.arange(P, dtype=torch.int32, device=dev)
+        # trailing P floats of the reduce buffer carry the "touched" flags so that ONE collective moves both
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.loss_beta, self.loss_variant = loss_beta, loss_variant
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        n = self.params[0].numel()
+        self._flat = torch.zeros(P * n + P, dtype=torch.float32, device=dev)
+        self.grads = self._flat[: P * n].view_as(self.params)
+        self._touched_f = self._flat[P * n:]
+
+    def step(self, pixel_values: torch.Tensor, label_color: torch.Tensor, yesdata: torch.Tensor,
+             prompt_idx: torch.Tensor, prompt_mask_color: torch.Tensor) -> torch.Tensor:
+        """One optimiser step on this rank's batch; returns this rank's loss (device scalar, no sync)."""
+        m = self.model
+        B = pixel_values.shape[0]
+        self._flat.zero_()
+        prompts = ops.prompt_gather(self.params, prompt_idx)  # stack + Normalize
+        pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True)
+        loss, gpred = ops.loss_fwd_bwd(pred, label_color, yesdata, self.loss_beta, self.loss_variant, True)
+        gpix = m._run_backward(gpred, B)
+        ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
+        self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
+        if self.world > 1:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.pg)  # RCCL over xGMI
+        touched = (self._touched_f > 0).to(torch.uint8)
+        self.steps += touched.long()
+        ops.adamw_step(self.params.view(self.params.shape[0], -1), self.grads.view(self.params.shape[0], -1),
+                       self.exp_avg.view(self.params.shape[0], -1), self.exp_avg_sq.view(self.params.shape[0], -1),
+                       self.rows, self.steps.clamp_min(1), self.lr, self.betas, self.eps, self.weight_decay,
+                       grad_scale=1.0 / self.world, touched=touched)
+        return loss.detach()

@@ -30,24 +30,28 @@ def _need_gpu(*ts):
             raise N.NativeError("beach_seg_amd.ops run on the MI355X only: tensor is on the CPU")
 
 
+def loss_fwd_bwd(pred, labels, yes, beta: float, variant: str, want_grad: bool):
+    """One fused kernel pass: (loss scalar, d loss / d pred or None).  No autograd involved."""
+    lib = N.load()
+    B, _, H2, W = pred.shape
+    h = H2 // 2
+    pred_c = pred.detach().float().contiguous()
+    labels_c = labels.detach().float().contiguous()
+    yes_c = yes.reshape(B, h, W).to(torch.uint8).contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred_c) if want_grad else None
+    scratch = torch.empty(lib.bsg_loss_scratch_bytes(h, W), dtype=torch.uint8, device=pred.device)
+    with torch.cuda.device(pred.device):
+        N.check(lib.bsg_loss_fwd_bwd(_stream(), B, h, W, _ptr(pred_c), _ptr(labels_c), _ptr(yes_c), float(beta),
+                                     VARIANTS[variant], _ptr(loss), _ptr(grad), _ptr(scratch), scratch.numel()))
+    return loss[0], grad
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, labels, yes, beta, variant):
-        lib = N.load()
-        B, _, H2, W = pred.shape
-        h = H2 // 2
-        pred_c = pred.detach().float().contiguous()
-        labels_c = labels.detach().float().contiguous()
-        yes_c = yes.reshape(B, h, W).to(torch.uint8).contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-        need = pred.requires_grad
-        grad = torch.empty_like(pred_c) if need else None
-        scratch = torch.empty(lib.bsg_loss_scratch_bytes(h, W), dtype=torch.uint8, device=pred.device)
-        with torch.cuda.device(pred.device):
-            N.check(lib.bsg_loss_fwd_bwd(_stream(), B, h, W, _ptr(pred_c), _ptr(labels_c), _ptr(yes_c), float(beta),
-                                         VARIANTS[variant], _ptr(loss), _ptr(grad), _ptr(scratch), scratch.numel()))
-        ctx.grad = grad
-        return loss[0]
+        loss, ctx.grad = loss_fwd_bwd(pred, labels, yes, beta, variant, pred.requires_grad)
+        return loss
 
     @staticmethod
     def backward(ctx, g):
@@ -106,20 +110,24 @@ def prompt_grad_scatter(grad_pixels: torch.Tensor, idx: torch.Tensor, grad_param
                                             _ptr(grad_params)))
 
 
-def adamw_step(params, grads, exp_avg, exp_avg_sq, active: torch.Tensor, steps: list[int], lr: float,
-               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0) -> None:
+def adamw_step(params, grads, exp_avg, exp_avg_sq, active: torch.Tensor, steps, lr: float,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, grad_scale: float = 1.0,
+               touched: torch.Tensor | None = None) -> None:
     """torch.optim.AdamW step on rows `active` of the flat (P, n) buffers; `steps[a]` = that row's step count
-    after this update.  Bias corrections are formed on the host in double, as torch does."""
+    after this update (list of ints, or a device tensor: no host sync).  Bias corrections are formed in double,
+    as torch does.  `touched` (u8 per ROW) skips rows without a gradient."""
     _need_gpu(params, grads, exp_avg, exp_avg_sq, active)
     lib = N.load()
     n_active = active.numel()
-    ss = torch.tensor([lr / (1.0 - betas[0] ** t) for t in steps], dtype=torch.float32, device=params.device)
-    b2 = torch.tensor([(1.0 - betas[1] ** t) ** 0.5 for t in steps], dtype=torch.float32, device=params.device)
+    t = torch.as_tensor(steps, dtype=torch.float64, device=params.device)
+    ss = (lr / (1.0 - betas[0] ** t)).to(torch.float32)
+    b2 = ((1.0 - betas[1] ** t) ** 0.5).to(torch.float32)
     act = active.to(torch.int32).contiguous()
     row = params[0].numel()
     with torch.cuda.device(params.device):
         N.check(lib.bsg_adamw_step(_stream(), n_active, row, _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq),
-                                   _ptr(act), _ptr(ss), _ptr(b2), lr, betas[0], betas[1], eps, weight_decay, grad_scale))
+                                   _ptr(act), _ptr(touched), _ptr(ss), _ptr(b2), lr, betas[0], betas[1], eps,
+                                   weight_decay, grad_scale))
 
 
 def vote_paste(counter: torch.Tensor, masks: torch.Tensor, crops: torch.Tensor, crop_size: int) -> None:

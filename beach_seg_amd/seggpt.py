@@ -192,6 +192,21 @@ class SegGptNative(torch.nn.Module):
         N.check(self._lib.bsg_workspace_region(self._h, batch, int(train), name.encode(), layer, C.byref(off), C.byref(nb)))
         return self.workspace(batch, train)[off.value: off.value + nb.value]
 
+    PROFILE_CATEGORIES = ("gemm", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "conv3x3")
+
+    def profile(self, enable: bool) -> None:
+        N.check(self._lib.bsg_profile_reset(self._h))
+        N.check(self._lib.bsg_profile_enable(self._h, int(enable)))
+
+    def profile_read(self) -> dict:
+        """{category: (kernel ms, algorithmic flops, launches)} since `profile(True)`; waits for the events."""
+        out = {}
+        for i, name in enumerate(self.PROFILE_CATEGORIES):
+            ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+            N.check(self._lib.bsg_profile_read(self._h, i, C.byref(ms), C.byref(fl), C.byref(n)))
+            out[name] = (ms.value, fl.value, n.value)
+        return out
+
     def _run_forward(self, pix, prm, pmask, emb: int, train: bool) -> torch.Tensor:
         B = pix.shape[0]
         H, W = self.geometry.image_size

@@ -99,10 +99,13 @@ int bsg_prompt_grad_scatter(void* stream, int batch, int h, int w, const float* 
                             const float std[3], float* grad_params);
 
 /* torch.optim.AdamW step (src/model.py:398) on the `n_active` prompt rows listed in `active` (device i32).
- * step_sizes / bc2_sqrts: device f32 [n_active], lr/(1-beta1^t) and sqrt(1-beta2^t) per active row. */
+ * `touched` (device u8 indexed by ROW, may be NULL): rows with touched[row] == 0 are skipped entirely, the way
+ * torch skips a Parameter whose .grad is None.  step_sizes / bc2_sqrts: device f32 [n_active],
+ * lr/(1-beta1^t) and sqrt(1-beta2^t) of each listed row. */
 int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, const float* grads, float* exp_avg,
-                   float* exp_avg_sq, const int32_t* active, const float* step_sizes, const float* bc2_sqrts,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale);
+                   float* exp_avg_sq, const int32_t* active, const uint8_t* touched, const float* step_sizes,
+                   const float* bc2_sqrts, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float grad_scale);
 
 /* Predict-loop glue (src/predict.py:259-260, 120-159, 100): nearest-resize each (hin,win) u8 class mask to
  * (crop,crop), one-hot vote into the u8 (mh,mw,K) mosaic counters with clipping; crops i32 (n,4) =
@@ -110,6 +113,14 @@ int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, co
 int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int win, int crop,
                    const int32_t* crops, uint8_t* counter, int mh, int mw, int K);
 int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out);
+
+/* Optional per-launch timing (HIP events recorded on the caller's stream around the kernels of one category):
+ * 0 GEMM, 1 attention fwd, 2 attention bwd dQ, 3 attention bwd dK/dV, 4 3x3 conv.  bsg_profile_read waits for the
+ * recorded events and returns the summed kernel time, the summed ALGORITHMIC flops and the launch count since
+ * the last bsg_profile_reset.  Disabled by default (no events, nothing recorded). */
+int bsg_profile_enable(bsg_model* m, int enable);
+int bsg_profile_read(bsg_model* m, int category, double* total_ms, double* total_flops, long* launches);
+int bsg_profile_reset(bsg_model* m);
 
 const char* bsg_last_error(void);
 const char* bsg_build_info(void);
