@@ -58,6 +58,19 @@ def cpu_baseline(geometry, threads: int) -> dict:
                       f"{dt:.1f} s, no warm-up"}
 
 
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """Cores this process may actually use (cgroup / affinity share), capped at the 16 a 1-GPU box grants."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +104,9 @@ def main() -> None:
 
     g = getattr(SegGptGeometry, args.geometry)()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    log(f"rank {rank}/{world}: building {args.geometry} ({args.dtype}) on {dev}")
     model = SegGptNative(synth_state_dict(g, seed=0, device=dev), g, device=dev, dtype=dtype)
+    log("model ready")
     B, P = args.batch, args.prompts
     Hh, W = g.image_size[0] // 2, g.image_size[1]
     gen = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -113,6 +128,7 @@ def main() -> None:
     for _ in range(args.warmup):
         step()
     fence()
+    log("warm-up done")
     model.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -125,6 +141,7 @@ def main() -> None:
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
 
@@ -153,7 +170,8 @@ def main() -> None:
             "kernel_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0 for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, os.cpu_count() or 1)
+            log("timing the CPU oracle (one tile) ...")
+            out["cpu_baseline"] = cpu_baseline(g, host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
