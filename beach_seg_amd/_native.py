@@ -12,14 +12,14 @@ _LIB_PATH = Path(__file__).resolve().parent / "libbsg_hip.so"
 _lib = None
 
 BSG_DTYPE_F32, BSG_DTYPE_BF16 = 0, 1
-BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 18
+BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 19
 
 # every exported symbol of include/beach_seg_amd.h (tests check the library exports exactly these)
 SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm",
 )
 
 
@@ -73,6 +73,7 @@ def load():
     lib.bsg_profile_enable.argtypes = [vp, i]
     lib.bsg_profile_read.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.bsg_profile_reset.argtypes = [vp]
+    lib.bsg_op_gemm.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -20,6 +20,7 @@ enum EpiMode {
   EPI_PLAIN = 5,      // out[m][n] = T(acc)
   EPI_GELU_BWD = 6,   // out[m][n] = T(acc * gelu'(aux[m][n]))
   EPI_UNPATCH = 7,    // patch-embed dgrad: scatter rows into the (B,3,H/2,W) fp32 prompt-pixel gradient
+  EPI_RELPOS = 8,     // per head (blockIdx.y): q . [rel_pos_h; rel_pos_w]^T scattered into the relh / relw tables
 };
 
 struct GemmArgs {
@@ -42,7 +43,93 @@ struct GemmArgs {
   void* out2;
   const void* aux;  // T* (GELU_BWD pre-activation) or float* (resid / table)
   long ldaux;
+  // EPI_RELPOS: out = relh [S][nh][N][hp], out2 = relw [S][nh][N][32], out3/out4 = query-slot-major copies
+  // relhT [S][nh][hp][hp*32] / relwT [S][nh][32][hp*32] (may be null); blockIdx.y = head, A column offset head*64
+  void* out3;
+  void* out4;
+  int hp, nh;
+  float alpha;
 };
+
+// ---- shared epilogue: acc[ni][mi][r] = C[mw + mi*16 + (lane&15)][nw + ni*16 + 4*(lane>>4) + r]
+template <typename T, int EPI>
+DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, int head) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = mw + mi * 16 + frow;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = nw + ni * 16 + 4 * fchunk;
+      if (n >= g.N) continue;
+      f32x4 v = acc[ni][mi];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
+        const f32x4 b = *(const f32x4*)(g.bias + n);
+        v += b;
+      }
+      if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
+        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+      } else if (EPI == EPI_BIAS_GELU) {
+        if (g.out2)
+          *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
+            pack4<T>(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+      } else if (EPI == EPI_BIAS_RESID) {
+        const f32x4 r = *(const f32x4*)((const float*)g.aux + (long)m * g.ldaux + n);
+        *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
+      } else if (EPI == EPI_EMBED) {
+        const int s = m / g.tokens, t = m % g.tokens;
+        const int kind = s >= g.batch ? 1 : 0;
+        const f32x4 r = *(const f32x4*)((const float*)g.aux + ((long)kind * g.tokens + t) * g.ldaux + n);
+        *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
+      } else if (EPI == EPI_FEAT) {
+        // n = (p1*16 + p2)*64 + c  ->  pixel (ph*16 + p1, pw*16 + p2), channel c   (HF:559-572)
+        const int b = m / g.tokens, t = m % g.tokens;
+        const int ph = t / g.wp, pw = t % g.wp;
+        const int p1 = n >> 10, p2 = (n >> 6) & 15, c = n & 63;
+        const long o = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
+        *(typename Traits<T>::Vec4*)((T*)g.out + o) = pack4<T>(v[0], v[1], v[2], v[3]);
+      } else if (EPI == EPI_GELU_BWD) {
+        const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
+        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
+            pack4<T>(v[0] * gelu_grad_f(to_f32(h[0])), v[1] * gelu_grad_f(to_f32(h[1])),
+                     v[2] * gelu_grad_f(to_f32(h[2])), v[3] * gelu_grad_f(to_f32(h[3])));
+      } else if (EPI == EPI_RELPOS) {
+        // column n of [rel_pos_h (2hp-1 rows); rel_pos_w (2wp-1 rows)]: rel index r <-> key kh = qh + hp-1 - r
+        // (HF:236-266 at q_size == k_size); only the entries that land inside the key grid are stored.
+        const int s = m / g.tokens, q = m % g.tokens, qh = q / g.wp, qw = q % g.wp;
+        const long sh = (long)s * g.nh + head;
+        const int npad = g.hp * 32, qpad = qh * 32 + qw, nh_rel = 2 * g.hp - 1, nw_rel = 2 * g.wp - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = n + r;
+          const float val = v[r] * g.alpha;
+          if (nn < nh_rel) {
+            const int kh = qh + g.hp - 1 - nn;
+            if (kh >= 0 && kh < g.hp) {
+              ((float*)g.out)[(sh * g.tokens + q) * g.hp + kh] = val;
+              if (g.out3) ((float*)g.out3)[(sh * g.hp + kh) * npad + qpad] = val;
+            }
+          } else if (nn < nh_rel + nw_rel) {
+            const int kw = qw + g.wp - 1 - (nn - nh_rel);
+            if (kw >= 0 && kw < g.wp) {
+              ((float*)g.out2)[(sh * g.tokens + q) * 32 + kw] = val;
+              if (g.out4) ((float*)g.out4)[(sh * 32 + kw) * npad + qpad] = val;
+            }
+          }
+        }
+      } else if (EPI == EPI_UNPATCH) {
+        // rows m = (b, t) over the TOP half tokens only (a_rpg = tokens/2); n = c*256 + i*16 + j
+        const int half = g.tokens >> 1;
+        const int b = m / half, t = m % half;
+        const int ph = t / g.wp, pw = t % g.wp;
+        const int c = n >> 8, i = (n >> 4) & 15, j = n & 15;
+        const long o = (((long)b * 3 + c) * (g.himg >> 1) + ph * 16 + i) * g.wimg + pw * 16 + j;
+        *(f32x4*)((float*)g.out + o) = v;
+      }
+    }
+  }
+}
 
 template <typename T, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
@@ -63,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // activation tile is fetched from HBM once and the weight panel stays in the XCD's L2.
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm << 7, n0 = tn << 7;
+  const int head = blockIdx.y;  // EPI_RELPOS only (gridDim.y == 1 otherwise)
 
   // ---- per-lane source pointers (constant over K): 4 row groups of 8 rows per wave for A and for W
   const int prow = lane >> 3, pchunk = lane & 7;
@@ -82,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       const int ph = t / g.wp, pw = t % g.wp;
       base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
     }
+    if (EPI == EPI_RELPOS) base += head * 64;
     a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
     int n = n0 + r;
     if (n >= g.N) n = g.N - 1;
@@ -137,62 +226,276 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
   }
 
-  // ---- epilogue: acc[ni][mi][r] = C[m0 + wr*64 + mi*16 + (lane&15)][n0 + wc*64 + ni*16 + 4*(lane>>4) + r]
+  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk, head);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v2: 256 x 128 tile, 8 waves (4 x 2, same 64 x 64 wave tile), THREE LDS stages of 48 KB.  Two K tiles of LDS-DMA
+// stay in flight across the (raw) barrier behind a counted s_waitcnt vmcnt(6): one block per CU, two waves per
+// SIMD, never a vmcnt(0) inside the loop.
+template <typename T, int AMODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
+  constexpr int EPC = Traits<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int STAGE = 49152;  // A 256 x 128 B, then W 128 x 128 B
+  typedef typename Traits<T>::Chunk Chunk;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + 127) >> 7, tiles_m = (g.M + 255) >> 8;
+  const int nwg = tiles_m * tiles_n;
+  const int bid = xcd_remap(blockIdx.x, nwg);
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm << 8, n0 = tn << 7;
+  const int head = blockIdx.y;
+
+  const int prow = lane >> 3, pchunk = lane & 7;
+  const char* a_src[4];
+  const char* w_src[2];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wr * 64 + mi * 16 + frow;
-    if (m >= g.M) continue;
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + prow;
+    const int sc = pchunk ^ (r & 7);
+    int m = m0 + r;
+    if (m >= g.M) m = g.M - 1;
+    long base;
+    if (AMODE == A_PLAIN) {
+      base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
+    } else {
+      const int b = m / g.tokens, t = m % g.tokens;
+      const int ph = t / g.wp, pw = t % g.wp;
+      base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+    }
+    if (EPI == EPI_RELPOS) base += head * 64;
+    a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
+  }
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wc * 64 + ni * 16 + 4 * fchunk;
-      if (n >= g.N) continue;
-      f32x4 v = acc[ni][mi];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
-        const f32x4 b = *(const f32x4*)(g.bias + n);
-        v += b;
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + prow;
+    const int sc = pchunk ^ (r & 7);
+    int n = n0 + r;
+    if (n >= g.N) n = g.N - 1;
+    w_src[i] = (const char*)g.W + (long)n * g.K * sizeof(T) + sc * 16;
+  }
+
+  auto stage = [&](int kt, int st) {
+    const long k0 = (long)kt * BK;
+    long ka;
+    if (AMODE == A_PLAIN) ka = k0;
+    else ka = (k0 >> 10) * ((long)g.wimg * 64) + (k0 & 1023);
+    char* la = smem + st * STAGE + wave * 4096;
+    char* lw = smem + st * STAGE + 32768 + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(a_src[i] + ka * sizeof(T), la + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(w_src[i] + k0 * sizeof(T), lw + i * 1024);
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;  // 4 x 2 waves
+  const int frow = lane & 15, fchunk = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most the 6 DMAs of tile kt+1 are still outstanding
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's part of tile kt is in LDS; every wave is done reading tile kt-1
+    if (kt + 2 < nk) stage(kt + 2, st == 0 ? 2 : st - 1);  // stage of tile kt-1
+    const char* la = smem + st * STAGE;
+    const char* lw = la + 32768;
+    Chunk fa[2][4], fw[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + frow;
+        const int rw = wc * 64 + i * 16 + frow;
+        const int c = fchunk + 4 * ks;
+        fa[ks][i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+        fw[ks][i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
       }
-      if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
-        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-      } else if (EPI == EPI_BIAS_GELU) {
-        if (g.out2)
-          *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
-            pack4<T>(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
-      } else if (EPI == EPI_BIAS_RESID) {
-        const f32x4 r = *(const f32x4*)((const float*)g.aux + (long)m * g.ldaux + n);
-        *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
-      } else if (EPI == EPI_EMBED) {
-        const int s = m / g.tokens, t = m % g.tokens;
-        const int kind = s >= g.batch ? 1 : 0;
-        const f32x4 r = *(const f32x4*)((const float*)g.aux + ((long)kind * g.tokens + t) * g.ldaux + n);
-        *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
-      } else if (EPI == EPI_FEAT) {
-        // n = (p1*16 + p2)*64 + c  ->  pixel (ph*16 + p1, pw*16 + p2), channel c   (HF:559-572)
-        const int b = m / g.tokens, t = m % g.tokens;
-        const int ph = t / g.wp, pw = t % g.wp;
-        const int p1 = n >> 10, p2 = (n >> 6) & 15, c = n & 63;
-        const long o = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
-        *(typename Traits<T>::Vec4*)((T*)g.out + o) = pack4<T>(v[0], v[1], v[2], v[3]);
-      } else if (EPI == EPI_GELU_BWD) {
-        const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
-        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
-            pack4<T>(v[0] * gelu_grad_f(to_f32(h[0])), v[1] * gelu_grad_f(to_f32(h[1])),
-                     v[2] * gelu_grad_f(to_f32(h[2])), v[3] * gelu_grad_f(to_f32(h[3])));
-      } else if (EPI == EPI_UNPATCH) {
-        // rows m = (b, t) over the TOP half tokens only (a_rpg = tokens/2); n = c*256 + i*16 + j
-        const int half = g.tokens >> 1;
-        const int b = m / half, t = m % half;
-        const int ph = t / g.wp, pw = t % g.wp;
-        const int c = n >> 8, i = (n >> 4) & 15, j = n & 15;
-        const long o = (((long)b * 3 + c) * (g.himg >> 1) + ph * 16 + i) * g.wimg + pw * 16 + j;
-        *(f32x4*)((float*)g.out + o) = v;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) mma16(acc[ni][mi], fw[ks][ni], fa[ks][mi]);
+    st = st == 2 ? 0 : st + 1;
+  }
+  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk, head);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// v3: 256 x 256 tile, 8 waves (2 x 4; wave tile 128 x 64 = four 64 x 32 quadrants), two 64 KB LDS buffers.
+// A K tile is consumed in FOUR phases (one accumulator quadrant = 16 MFMAs each); every phase also issues one
+// 16 KB quarter of the NEXT K tile by LDS-DMA (2 per lane) and reads only the fragments its quadrant adds:
+//     phase 0: A rows mh0 (8 reads) + W rows nh0 (4)   | DMA Q0a = A rows mh0 of tile t+1
+//     phase 1: W rows nh1 (4)                           | DMA Q0b = W rows nh0
+//     phase 2: A rows mh1 (8)                           | DMA Q1  = W rows nh1
+//     phase 3: --                                       | DMA Q2  = A rows mh1
+// so every quarter is issued >= 3 phases before its first read and >= 5 phases after the last read of the
+// region it overwrites.  One counted `s_waitcnt vmcnt(4)` per phase (two quarters stay in flight across the
+// barriers; never vmcnt(0) in the loop), raw s_barrier, MFMA clusters under s_setprio.  Waves 4-7 run one barrier
+// behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while the other issues reads and DMA.
+template <typename T, int AMODE, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
+  constexpr int EPC = Traits<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int BUF = 65536;  // A 256 x 128 B, then W 256 x 128 B
+  typedef typename Traits<T>::Chunk Chunk;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + 255) >> 8, tiles_m = (g.M + 255) >> 8;
+  const int nwg = tiles_m * tiles_n;
+  int bid = xcd_remap(blockIdx.x, nwg);
+  // groups of 4 row tiles: the blocks resident on one XCD at a time share 4 activation panels and a few weight panels
+  const int gsz = 4 * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
+  const int gm = min(4, tiles_m - grp * 4);
+  const int tm = grp * 4 + rem % gm, tn = rem / gm;
+  const int m0 = tm << 8, n0 = tn << 8;
+  const int head = blockIdx.y;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- DMA sources: quarter q, instruction j = 2*wave + i (i = 0, 1) covers 8 rows
+  const int prow = lane >> 3, pchunk = lane & 7;
+  const char* src[4][2];
+  int ldsoff[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = 2 * wave + i;
+      int row;  // row inside the 256-row A (q = 0, 3) or W (q = 1, 2) tile
+      if (q == 0) row = (j >> 3) * 128 + (j & 7) * 8;            // A, mh0: rows wm'*128 + [0, 64)
+      else if (q == 3) row = (j >> 3) * 128 + 64 + (j & 7) * 8;  // A, mh1
+      else if (q == 1) row = (j >> 2) * 64 + (j & 3) * 8;        // W, nh0: rows wn'*64 + [0, 32)
+      else row = (j >> 2) * 64 + 32 + (j & 3) * 8;               // W, nh1
+      const int r = row + prow;
+      const int sc = pchunk ^ (r & 7);
+      const bool is_a = (q == 0 || q == 3);
+      ldsoff[q][i] = (is_a ? 0 : 32768) + row * 128;
+      if (is_a) {
+        int m = m0 + r;
+        if (m >= g.M) m = g.M - 1;
+        long base;
+        if (AMODE == A_PLAIN) {
+          base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
+        } else {
+          const int b = m / g.tokens, t = m % g.tokens;
+          const int ph = t / g.wp, pw = t % g.wp;
+          base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+        }
+        if (EPI == EPI_RELPOS) base += head * 64;
+        src[q][i] = (const char*)g.A + base * sizeof(T) + sc * 16;
+      } else {
+        int n = n0 + r;
+        if (n >= g.N) n = g.N - 1;
+        src[q][i] = (const char*)g.W + (long)n * g.K * sizeof(T) + sc * 16;
       }
     }
+  auto issue = [&](int q, int kt, int buf) {
+    const long k0 = (long)kt * BK;
+    long koff = k0;
+    if (AMODE == A_FEAT && (q == 0 || q == 3)) koff = (k0 >> 10) * ((long)g.wimg * 64) + (k0 & 1023);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(src[q][i] + koff * sizeof(T), smem + buf * BUF + ldsoff[q][i]);
+  };
+
+  const int frow = lane & 15, fchunk = lane >> 4;
+  f32x4 acc[2][4][4];  // [mh][ni = nh*2 + j][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue(q, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  if (wm == 1) asm volatile("s_barrier" ::: "memory");  // stagger: waves 4-7 run one barrier behind
+
+  Chunk af[2][4], bf[2][2][2];
+  auto read_a = [&](const char* la, int mh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 128 + mh * 64 + i * 16 + frow, c = fchunk + 4 * ks;
+        af[ks][i] = *(const Chunk*)(la + r * 128 + ((c ^ (r & 7)) << 4));
+      }
+  };
+  auto read_b = [&](const char* lw, int nh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + nh * 32 + j * 16 + frow, c = fchunk + 4 * ks;
+        bf[nh][ks][j] = *(const Chunk*)(lw + r * 128 + ((c ^ (r & 7)) << 4));
+      }
+  };
+  auto mfma_quadrant = [&](int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma16(acc[mh][nh * 2 + j][i], bf[nh][ks][j], af[ks][i]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const char* la = smem + buf * BUF;
+    const char* lw = la + 32768;
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p == 0) { read_b(lw, 0); read_a(la, 0); }
+      else if (p == 1) read_b(lw, 1);
+      else if (p == 2) read_a(la, 1);
+      if (more) {
+        issue(p, kt + 1, buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");
+      mfma_quadrant(p >> 1, (p == 1 || p == 2) ? 1 : 0);
+      asm volatile("s_barrier" ::: "memory");
+    }
   }
+  if (wm == 0) asm volatile("s_barrier" ::: "memory");  // balance the stagger
+  gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk, head);
+  gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk, head);
 }
 
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
+  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 3;
+  const dim3 gy(1, EPI == EPI_RELPOS ? g.nh : 1);
+  if (ver == 1) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(256), 65536, st, g);
+  } else if (ver == 2 || g.N <= 192) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(512), 3 * 49152, st, g);
+  } else {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(512), 131072, st, g);
+  }
 }

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,7 +54,7 @@ struct ProfRec { int cat; double flops; hipEvent_t e0, e1; };
 struct bsg_model {
   bsg_config c;
   std::vector<const void*> w;
-  int hp, wp, N, npad, es;
+  int hp, wp, N, npad, es, relcat_rows;
   bool prof = false;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> pool;
@@ -141,10 +142,11 @@ template <typename K> static void allow_lds(K kernel, int bytes) {
 
 // ------------------------------------------------------------------------------------------- launch helpers
 template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, GemmArgs g, hipStream_t st) {
-  static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), true);
+  static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
+                      allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
   if (g.a_rpg <= 0) { g.a_rpg = g.M > 0 ? g.M : 1; g.a_gstride = 0; }
-  ProfScope ps(m, st, PC_GEMM, 2.0 * g.M * g.N * g.K);
+  ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
   launch_gemm<T, AM, EPI>(g, st);
 }
 
@@ -218,13 +220,13 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       CHECK_LAUNCH();
     }
     {
-      const int lds = (64 + 2 * hp - 1 + 2 * wp - 1) * 65 * 4;
-      static bool once = (allow_lds(relpos_fwd_kernel<T>, 160 * 1024), true);
-      (void)once;
-      hipLaunchKernelGGL((relpos_fwd_kernel<T>), dim3((N + 63) / 64, nh, S), dim3(256), lds, st, qkv, (long)3 * D,
-                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), relh, relw, (float*)nullptr,
-                         (float*)nullptr, N, hp, wp, nh, 1.0f / scale);
-      CHECK_LAUNCH();
+      {
+        GemmArgs g{};
+        g.A = qkv; g.W = m->lw(l, 18); g.M = rows; g.N = m->relcat_rows; g.K = 64; g.lda = 3 * D; g.tokens = N; g.wp = wp;
+        g.hp = hp; g.nh = nh; g.alpha = 1.0f / scale; g.out = relh; g.out2 = relw;
+        gemm<T, A_PLAIN, EPI_RELPOS>(m, g, st);
+        CHECK_LAUNCH();
+      }
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
                          wp, nh);
       CHECK_LAUNCH();
@@ -398,11 +400,13 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)dn_b, attn_o, (long)D, delta,
                          B, N, hp, wp, nh);
       CHECK_LAUNCH();
-      const int lds = (64 + 2 * hp - 1 + 2 * wp - 1) * 65 * 4;
-      hipLaunchKernelGGL((relpos_fwd_kernel<T>), dim3((N + 63) / 64, nh, B), dim3(256), lds, st, qkv, (long)3 * D,
-                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), relh, relw, relhT, relwT, N, hp, wp, nh,
-                         1.0f / scale);
-      CHECK_LAUNCH();
+      {
+        GemmArgs g{};
+        g.A = qkv; g.W = m->lw(l, 18); g.M = rows; g.N = m->relcat_rows; g.K = 64; g.lda = 3 * D; g.tokens = N; g.wp = wp;
+        g.hp = hp; g.nh = nh; g.alpha = 1.0f / scale; g.out = relh; g.out2 = relw; g.out3 = relhT; g.out4 = relwT;
+        gemm<T, A_PLAIN, EPI_RELPOS>(m, g, st);
+        CHECK_LAUNCH();
+      }
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh);
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh);
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
@@ -487,7 +491,7 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   bsg_model* m = new bsg_model();
   m->c = c;
   m->w.assign(weights, weights + need);
-  m->hp = hp; m->wp = wp; m->N = hp * wp; m->npad = hp * 32; m->es = c.dtype == BSG_DTYPE_F32 ? 4 : 2;
+  m->hp = hp; m->wp = wp; m->N = hp * wp; m->npad = hp * 32; m->relcat_rows = ((2 * hp - 1 + 2 * wp - 1) + 3) & ~3; m->es = c.dtype == BSG_DTYPE_F32 ? 4 : 2;
   *out = m;
   return 0;
 }
@@ -631,6 +635,19 @@ int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, co
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)std::min<long>((row_elems + 255) / 256, 4096), n_active), dim3(256), 0,
                      (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (const int*)active, touched, step_sizes, bc2_sqrts,
                      row_elems, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias, void* out) {
+  if (!A || !W || !out) return fail("bsg_op_gemm: null argument");
+  if (K % (dtype == BSG_DTYPE_F32 ? 32 : 64) || N % 4) return fail("bsg_op_gemm: K must be a multiple of the 128-byte K tile, N of 4");
+  bsg_model dummy{};
+  GemmArgs g{};
+  g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.out = out; g.ldo = N;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == BSG_DTYPE_F32) { if (bias) gemm<float, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<float, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
+  else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
   CHECK_LAUNCH();
   return 0;
 }

@@ -151,3 +151,17 @@ def vote_argmax(counter: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(counter.device):
         N.check(lib.bsg_vote_argmax(_stream(), _ptr(counter), mh * mw, K, _ptr(out)))
     return out
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16 or both f32."""
+    _need_gpu(a, w, bias)
+    lib = N.load()
+    if a.dtype != w.dtype or a.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("a and w must both be float32 or both bfloat16")
+    M, K = a.shape
+    out = torch.empty((M, w.shape[0]), dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        N.check(lib.bsg_op_gemm(_stream(), 0 if a.dtype == torch.float32 else 1, M, w.shape[0], K, _ptr(a.contiguous()),
+                                _ptr(w.contiguous()), _ptr(bias), _ptr(out)))
+    return out

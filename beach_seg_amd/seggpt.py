@@ -64,6 +64,13 @@ def token_tables(sd: dict, g: SegGptGeometry) -> tuple[torch.Tensor, torch.Tenso
     return out[0], out[1]
 
 
+def _rel_cat(rel_h: torch.Tensor, rel_w: torch.Tensor) -> torch.Tensor:
+    """[rel_pos_h; rel_pos_w] padded with zero rows to a multiple of 4 rows (operand of the rel-pos table GEMM)."""
+    cat = torch.cat([rel_h.detach().float(), rel_w.detach().float()], 0)
+    pad = (-cat.shape[0]) % 4
+    return torch.cat([cat, cat.new_zeros(pad, cat.shape[1])], 0) if pad else cat
+
+
 def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) -> list[torch.Tensor]:
     """Device tensors in the slot order documented in `include/beach_seg_amd.h`."""
     missing = [k for k in state_dict_shapes(g) if k not in sd]
@@ -111,6 +118,7 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) 
             f32(sd[l + "layernorm_after.weight"]), f32(sd[l + "layernorm_after.bias"]),
             w1, w1T, f32(sd[l + "mlp.lin1.bias"]), w2, w2T, f32(sd[l + "mlp.lin2.bias"]),
             f32(sd[l + "attention.rel_pos_h"]), f32(sd[l + "attention.rel_pos_w"]),
+            T(_rel_cat(sd[l + "attention.rel_pos_h"], sd[l + "attention.rel_pos_w"])),
         ]
     return table
 

@@ -27,7 +27,7 @@ extern "C" {
 #define BSG_DTYPE_BF16 1 /* throughput mode: bf16 storage / bf16 MFMA, fp32 accumulate + fp32 residual stream */
 #define BSG_MAX_TAPS 8
 #define BSG_GLOBAL_WEIGHTS 16 /* weight-table slots before the per-layer blocks */
-#define BSG_LAYER_WEIGHTS 18  /* slots per encoder layer */
+#define BSG_LAYER_WEIGHTS 19  /* slots per encoder layer */
 
 /* Mirror of the SegGptConfig fields the path reads (HF:configuration_seggpt.py:57-75). */
 typedef struct bsg_config {
@@ -48,8 +48,9 @@ typedef struct bsg_model bsg_model;
  *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*64][taps*D]
  *         7 dec_wT T[taps*D][256*64]   8 dec_b f32   9 conv_w T[64 co][9][64 ci]   10 conv_wT T[64 ci][9][64 co]
  *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][64]   15 head_b f32[3]
- * layer l at 16 + 18*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
+ * layer l at 16 + 19*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
  *         10 fc1_w 11 fc1_wT 12 fc1_b 13 fc2_w 14 fc2_wT 15 fc2_b 16 rel_pos_h f32[2Hp-1][64] 17 rel_pos_w f32
+ *         18 rel_cat T[roundup4(2Hp-1 + 2Wp-1)][64] = [rel_pos_h; rel_pos_w; zero rows]
  * tok_table[kind][t] folds conv bias (or mask_token for masked tokens of the mask stream), segment token,
  * bicubic-resized position embedding and type token (HF:163-206): pure constants of the checkpoint. */
 int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights, bsg_model** out);
@@ -113,6 +114,11 @@ int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, co
 int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int win, int crop,
                    const int32_t* crops, uint8_t* counter, int mh, int mw, int K);
 int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out);
+
+/* The NT GEMM kernel on its own (unit tests and micro-benchmarks): out[M][N] = A[M][K] W[N][K]^T (+ bias[N]),
+ * A / W / out in the dtype given (0 f32, 1 bf16), bias f32 or NULL. */
+int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,
+                void* out);
 
 /* Optional per-launch timing (HIP events recorded on the caller's stream around the kernels of one category):
  * 0 GEMM, 1 attention fwd, 2 attention bwd dQ, 3 attention bwd dK/dV, 4 3x3 conv.  bsg_profile_read waits for the
