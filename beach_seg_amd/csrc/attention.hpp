@@ -353,17 +353,42 @@ struct AttnBwdKvArgs {
   float scale;
 };
 
+// LDS-DMA of a ROWS x RB-byte tile by NW waves (1 KiB per wave-instruction), optional chunk swizzle.
+template <int RB, int ROWS, int NW, bool SWZ, typename RowSrc>
+DEVI void dma_rows(char* lds_tile, int wave, int lane, RowSrc row_src) {
+  constexpr int CPR = RB / 16, RPI = 64 / CPR, NI = ROWS / RPI;
+#pragma unroll
+  for (int j0 = 0; j0 < NI; j0 += NW) {
+    const int j = j0 + wave;
+    if (NI % NW == 0 || j < NI) {
+      const int r = j * RPI + lane / CPR, p = lane % CPR;
+      const char* src = row_src(r) + ((SWZ ? (p ^ swz<RB>(r)) : p) << 4);
+      glds16(src, lds_tile + j * 1024);
+    }
+  }
+}
+
+template <typename T> struct DkvK {
+  static constexpr int TILE = AttnK<T>::TILE;
+  static constexpr int STAGE = 4 * TILE + 8192 + 4096;  // Q | dO | QT | dOT | relwT [32][64 f32] | stats [16][64 f32]
+};
+
+// Eight waves per workgroup, each owning ONE grid row of keys (32 slots): dK^T, dV^T of that row stay in 64
+// accumulator registers, so two waves fit per SIMD.  The per-query statistics (lse2, delta, rel-pos rows) ride the
+// same LDS-DMA stream as the Q / dO tiles instead of occupying 128 registers.
 template <typename T>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][Q | dO | QT | dOT][TILE]
+  constexpr int RB = C::RB, STAGE = DkvK<T>::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, s = blockIdx.z;
   const int nt = a.hp >> 1;
-  const int kt = min(blockIdx.x * 4 + wave, nt - 1);  // this wave's key tile (clamped: duplicates do not store)
-  const bool wave_valid = blockIdx.x * 4 + wave < nt;
+  const int kr0 = blockIdx.x * 8;
+  const bool wave_valid = kr0 + wave < a.hp;
+  const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
   const long sh = (long)s * a.nh + head;
   const int npad = a.hp * 32;
   const char* qbase = (const char*)a.q + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
@@ -371,115 +396,109 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   const char* qtbase = (const char*)a.qt + sh * 64 * npad * sizeof(T);
   const char* dotbase = (const char*)a.dot + sh * 64 * npad * sizeof(T);
 
-  // K, V fragments of this wave's 64 key slots (B operands), loop-invariant
-  Chunk kf[2][C::KS_D], vf[2][C::KS_D];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const long tok = (long)s * a.N + slot_token(2 * kt + b, col, a.wp);
+  Chunk kf[C::KS_D], vf[C::KS_D];
+  {
+    const long tok = (long)s * a.N + slot_token(kr, col, a.wp);
     const char* krow = (const char*)a.k + (tok * a.ld + head * 64) * sizeof(T);
     const char* vrow = (const char*)a.v + (tok * a.ld + head * 64) * sizeof(T);
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) {
-      kf[b][ks] = *(const Chunk*)(krow + (2 * ks + h) * 16);
-      vf[b][ks] = *(const Chunk*)(vrow + (2 * ks + h) * 16);
+      kf[ks] = *(const Chunk*)(krow + (2 * ks + h) * 16);
+      vf[ks] = *(const Chunk*)(vrow + (2 * ks + h) * 16);
     }
   }
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool key_valid = col < a.wp;
-  f32x16 dkt[2][2], dvt[2][2];  // [d block][key block]
+  f32x16 dkt[2], dvt[2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    dkt[0][0][i] = dkt[0][1][i] = dkt[1][0][i] = dkt[1][1][i] = 0.f;
-    dvt[0][0][i] = dvt[0][1][i] = dvt[1][0][i] = dvt[1][1][i] = 0.f;
-  }
-  const float* relwT = a.relwT + (sh * 32 + col) * npad;  // + q slot
-  const float* relhT0 = a.relhT + (sh * a.hp + 2 * kt) * npad;
-  const float* lse2 = a.lse2 + sh * npad;
-  const float* delta = a.delta + sh * npad;
+  for (int i = 0; i < 16; ++i) { dkt[0][i] = dkt[1][i] = dvt[0][i] = dvt[1][i] = 0.f; }
 
   auto issue = [&](int t, int buf) {
-    char* q_l = smem + buf * 4 * C::TILE;
-    dma_tile<T>(q_l, wave, lane, [&](int r) {
+    char* base = smem + buf * STAGE;
+    dma_rows<RB, 64, 8, true>(base, wave, lane, [&](int r) {
       return qbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
     });
-    dma_tile<T>(q_l + C::TILE, wave, lane, [&](int r) {
+    dma_rows<RB, 64, 8, true>(base + C::TILE, wave, lane, [&](int r) {
       return dobase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ldo * sizeof(T);
     });
-    dma_tile<T>(q_l + 2 * C::TILE, wave, lane, [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
-    dma_tile<T>(q_l + 3 * C::TILE, wave, lane, [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_rows<RB, 64, 8, true>(base + 2 * C::TILE, wave, lane,
+                              [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_rows<RB, 64, 8, true>(base + 3 * C::TILE, wave, lane,
+                              [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_rows<256, 32, 8, true>(base + 4 * C::TILE, wave, lane, [&](int r) {
+      return (const char*)(a.relwT + (sh * 32 + r) * npad + t * 64);
+    });
+    dma_rows<256, 16, 8, false>(base + 4 * C::TILE + 8192, wave, lane, [&](int r) {
+      const float* p = r == 0 ? a.lse2 + sh * npad
+                     : r == 1 ? a.delta + sh * npad
+                              : a.relhT + (sh * a.hp + min(kr0 + max(r - 2, 0), a.hp - 1)) * npad;
+      return (const char*)(p + t * 64);
+    });
   };
 
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    // per-row statistics of the 64 query slots of this step (issued BEFORE the next DMA: vmcnt is in-order)
-    f32x4 lsev[2][4], dlv[2][4], rwv[2][4], rhv[2][2][4];
-#pragma unroll
-    for (int qa = 0; qa < 2; ++qa)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int qs = t * 64 + qa * 32 + 8 * i + 4 * h;  // padded q slot of registers 4i..4i+3
-        lsev[qa][i] = *(const f32x4*)(lse2 + qs);
-        dlv[qa][i] = *(const f32x4*)(delta + qs);
-        rwv[qa][i] = *(const f32x4*)(relwT + qs);
-        rhv[qa][0][i] = *(const f32x4*)(relhT0 + qs);
-        rhv[qa][1][i] = *(const f32x4*)(relhT0 + npad + qs);
-      }
     wait_vm0();
     __syncthreads();
     if (t + 1 < nt) issue(t + 1, buf ^ 1);
-    const char* q_l = smem + buf * 4 * C::TILE;
+    const char* q_l = smem + buf * STAGE;
     const char* do_l = q_l + C::TILE;
     const char* qt_l = q_l + 2 * C::TILE;
     const char* dot_l = q_l + 3 * C::TILE;
+    const char* rw_l = q_l + 4 * C::TILE + col * 256;
+    const char* st_l = q_l + 4 * C::TILE + 8192;
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
+      f32x16 st, dp;
+      f32x4 lse4[4], dl4[4];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        f32x16 st, dp;
+      for (int i = 0; i < 4; ++i) {
+        const int c = qa * 8 + 2 * i + h;  // 16-byte chunk holding query slots qa*32 + 8i + 4h .. +3
+        lse4[i] = *(const f32x4*)(st_l + c * 16);
+        dl4[i] = *(const f32x4*)(st_l + 256 + c * 16);
+        const f32x4 rh = *(const f32x4*)(st_l + (2 + wave) * 256 + c * 16);
+        const f32x4 rw = *(const f32x4*)(rw_l + ((c ^ (col & 15)) << 4));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = rwv[qa][r >> 2][r & 3] + rhv[qa][b][r >> 2][r & 3]; dp[r] = 0.f; }
+        for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j] + rh[j]; dp[4 * i + j] = 0.f; }
+      }
 #pragma unroll
-        for (int ks = 0; ks < C::KS_D; ++ks) {
-          mma32(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kf[b][ks]);
-          mma32(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vf[b][ks]);
-        }
+      for (int ks = 0; ks < C::KS_D; ++ks) {
+        mma32(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kf[ks]);
+        mma32(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vf[ks]);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool ok = key_valid && acc32_row(r, h) < a.wp;
-          const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lsev[qa][r >> 2][r & 3]) : 0.f;
-          st[r] = p;                                                   // P
-          dp[r] = ok ? p * (dp[r] - dlv[qa][r >> 2][r & 3]) : 0.f;      // dS
-        }
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = key_valid && acc32_row(r, h) < a.wp;
+        const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lse4[r >> 2][r & 3]) : 0.f;
+        st[r] = p;                                               // P
+        dp[r] = ok ? p * (dp[r] - dl4[r >> 2][r & 3]) : 0.f;      // dS
+      }
 #pragma unroll
-        for (int ks = 0; ks < C::KS_B; ++ks) {
-          const Chunk pb = acc_chunk(st, ks, T());
-          const Chunk dsb = acc_chunk(dp, ks, T());
+      for (int ks = 0; ks < C::KS_B; ++ks) {
+        const Chunk pb = acc_chunk(st, ks, T());
+        const Chunk dsb = acc_chunk(dp, ks, T());
 #pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            mma32(dvt[d][b], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
-            mma32(dkt[d][b], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
-          }
+        for (int d = 0; d < 2; ++d) {
+          mma32(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
+          mma32(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
         }
       }
     }
   }
   if (wave_valid && key_valid) {
+    const long tok = (long)s * a.N + kr * a.wp + col;
+    T* dkrow = (T*)a.dk + tok * a.ld + head * 64;
+    T* dvrow = (T*)a.dv + tok * a.ld + head * 64;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const long tok = (long)s * a.N + (2 * kt + b) * a.wp + col;
-      T* dkrow = (T*)a.dk + tok * a.ld + head * 64;
-      T* dvrow = (T*)a.dv + tok * a.ld + head * 64;
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          *(typename Traits<T>::Vec4*)(dkrow + 32 * d + 8 * i + 4 * h) =
-              pack4<T>(dkt[d][b][4 * i] * a.scale, dkt[d][b][4 * i + 1] * a.scale, dkt[d][b][4 * i + 2] * a.scale,
-                       dkt[d][b][4 * i + 3] * a.scale);
-          *(typename Traits<T>::Vec4*)(dvrow + 32 * d + 8 * i + 4 * h) =
-              pack4<T>(dvt[d][b][4 * i], dvt[d][b][4 * i + 1], dvt[d][b][4 * i + 2], dvt[d][b][4 * i + 3]);
-        }
-    }
+      for (int i = 0; i < 4; ++i) {
+        *(typename Traits<T>::Vec4*)(dkrow + 32 * d + 8 * i + 4 * h) =
+            pack4<T>(dkt[d][4 * i] * a.scale, dkt[d][4 * i + 1] * a.scale, dkt[d][4 * i + 2] * a.scale,
+                     dkt[d][4 * i + 3] * a.scale);
+        *(typename Traits<T>::Vec4*)(dvrow + 32 * d + 8 * i + 4 * h) =
+            pack4<T>(dvt[d][4 * i], dvt[d][4 * i + 1], dvt[d][4 * i + 2], dvt[d][4 * i + 3]);
+      }
   }
 }

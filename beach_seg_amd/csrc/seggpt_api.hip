@@ -434,11 +434,11 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
-      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T>, 8 * AttnK<T>::TILE), true);
+      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T>, 2 * DkvK<T>::STAGE), true);
       (void)once2;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp / 2 + 3) / 4, nh, B), dim3(256), 8 * AttnK<T>::TILE, st, k);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp + 7) / 8, nh, B), dim3(512), 2 * DkvK<T>::STAGE, st, k);
       }
       CHECK_LAUNCH();
     }
