@@ -1,0 +1,143 @@
+"""Tile-loader surface of `/root/reference/src/data.py` on synthetic / in-memory rasters.
+
+Kept: the `BeachSegDataset.__getitem__` dictionary `{crop_idx, date, image f32(3,S,S) in [0,1], mask u8(S,S),
+nodata bool(S,S)}` (`src/data.py:118-124`), the resize rules (`:93-113`: PIL bicubic for the image, nearest for
+mask / nodata), the "hack" that marks valid pixels as class 1 when no label exists (`:115-116`), and the
+DataModule attributes the model reads (`prompt_imgs`, `normalize`, `denormalize`, `aug`, `train_aug`).
+Replaced: GeoTIFF / shapefile IO (rasterio, geopandas: absent here) by in-memory
+arrays; the 4-band -> RGB collapse follows `tif_image` (`src/util/geo_util.py:449-470`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import ml_util
+from .config import BeachSegConfig
+
+
+def tif_image(bands: np.ndarray, nodata: np.ndarray | None = None) -> np.ndarray:
+    """4-band (B,G,R,NIR) or 8-band surface-reflectance raster (C,H,W) -> uint8 (H,W,3), as
+    `src/util/geo_util.py:449-470`: pick R,G,B, clip to [min, min+3000], divide by the per-channel max, x255."""
+    b = bands.astype(np.float32)
+    if b.shape[0] == 4:
+        rgb = np.stack([b[2], b[1], b[0]], axis=-1)
+    elif b.shape[0] == 8:
+        rgb = np.stack([b[5], b[3], b[1]], axis=-1)
+    else:
+        raise ValueError(f"expected 4 or 8 bands, got {b.shape[0]}")
+    lo = rgb.min()
+    rgb = np.clip(rgb, lo, lo + 3000.0) - lo
+    mx = rgb.reshape(-1, 3).max(axis=0)
+    rgb = rgb / np.maximum(mx, 1e-6)
+    out = (rgb * 255.0).astype(np.uint8)
+    if nodata is not None:
+        out[nodata] = 0
+    return out
+
+
+def padded_crop(arr: np.ndarray, crop: tuple[int, int, int, int], fill=0) -> np.ndarray:
+    """`src/util/geo_util.py:316-341`: window (xmin,ymin,xmax,ymax) that may stick out of the raster."""
+    xmin, ymin, xmax, ymax = crop
+    h, w = arr.shape[:2]
+    out = np.full((ymax - ymin, xmax - xmin) + arr.shape[2:], fill, dtype=arr.dtype)
+    dy0, dy1, dx0, dx1 = max(ymin, 0), min(ymax, h), max(xmin, 0), min(xmax, w)
+    if dy1 > dy0 and dx1 > dx0:
+        out[dy0 - ymin: dy1 - ymin, dx0 - xmin: dx1 - xmin] = arr[dy0:dy1, dx0:dx1]
+    return out
+
+
+class BeachSegDataset(torch.utils.data.Dataset):
+    """`src/data.py:37-127` over in-memory rasters: date -> (rgb u8 (H,W,3), nodata bool (H,W)), optional masks."""
+
+    def __init__(self, date_merged_imgs: dict, date_masks: dict | None, crops: list[tuple[int, int, int, int]],
+                 config: BeachSegConfig, create_prompts: bool = False):
+        self.date_merged_imgs, self.date_masks = date_merged_imgs, date_masks or {}
+        self.crops, self.config = crops, config
+        self.imgs = [{"date": d, "crop_idx": i} for d in date_merged_imgs for i in range(len(crops))]
+        if create_prompts:
+            self.prompt_imgs = [self.get_crop(x) for x in self.imgs]  # src/data.py:74-76
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def get_crop(self, img_data: dict) -> dict:
+        c = self.config
+        date, crop_idx = img_data["date"], img_data["crop_idx"]
+        crop = self.crops[crop_idx]
+        img, nodata = self.date_merged_imgs[date]
+        label = self.date_masks.get(date)
+        crop_img = padded_crop(img, crop)
+        crop_nodata = padded_crop(nodata, crop, fill=True)
+        crop_label = padded_crop(label, crop) if label is not None else np.zeros(crop_img.shape[:2], np.uint8)
+        S = c.inpt_size
+        if S != c.crop_size:
+            res = getattr(Image.Resampling, c.resample) if isinstance(c.resample, str) else c.resample
+            crop_img = np.array(Image.fromarray(crop_img).resize((S, S), resample=res))
+            crop_label = np.array(Image.fromarray(crop_label).resize((S, S), resample=Image.Resampling.NEAREST))
+            crop_nodata = np.array(Image.fromarray(crop_nodata).resize((S, S), resample=Image.Resampling.NEAREST))
+        crop_img = crop_img.astype(np.float32) / 255.0
+        if not np.all(crop_nodata) and np.all(crop_label == 0):  # src/data.py:115-116
+            crop_label = crop_label.copy()
+            crop_label[~crop_nodata] = 1
+        return {"crop_idx": crop_idx, "date": date, "image": crop_img.transpose(2, 0, 1).copy(),
+                "mask": crop_label, "nodata": crop_nodata}
+
+    def __getitem__(self, idx):
+        return self.get_crop(self.imgs[idx])
+
+
+def synthetic_dove_scene(seed: int = 1234, size: int = 256, n_dates: int = 1) -> tuple[dict, dict]:
+    """uint16 4-band tiles U[200, 3200), block-structured labels 1..3."""
+    rng = np.random.default_rng(seed)
+    imgs, masks = {}, {}
+    for d in range(n_dates):
+        bands = rng.integers(200, 3200, size=(4, size, size), dtype=np.uint16)
+        lab = rng.integers(1, 4, size=(size // 32, size // 32), dtype=np.uint8).repeat(32, 0).repeat(32, 1)
+        date = f"2025-01-{d + 1:02d}"
+        imgs[date] = (tif_image(bands), np.zeros((size, size), bool))
+        masks[date] = lab
+    return imgs, masks
+
+
+class BeachSegDataModule:
+    """The attributes `PromptModel` / the drivers read from `src/data.py:181-346`."""
+
+    def __init__(self, config: BeachSegConfig, scene: tuple[dict, dict] | None = None,
+                 crops: list[tuple[int, int, int, int]] | None = None):
+        self.config = config
+        self.mean, self.std = ml_util.IMAGE_MEAN, ml_util.IMAGE_STD
+        self.normalize, self.denormalize = ml_util.normalize, ml_util.denormalize
+        self.scene = scene or synthetic_dove_scene()
+        size = next(iter(self.scene[0].values()))[0].shape[0]
+        cs = config.crop_size
+        self.crops = crops or [(x, y, x + cs, y + cs) for y in range(0, size, cs) for x in range(0, size, cs)]
+
+    def aug(self, batch: dict) -> dict:  # CenterCrop(inpt_size) is the identity at native size; Normalize
+        out = dict(batch)
+        out["image"] = self.normalize(batch["image"])
+        return out
+
+    train_aug = aug  # kornia's random flips / colour jitter / erasing / noise: SURVEY.md section 8 f-4 ("next")
+
+    def setup(self, stage: str) -> None:
+        imgs, masks = self.scene
+        if stage in ("fit", "train", "validate"):
+            self.train_dataset = BeachSegDataset(imgs, masks, self.crops, self.config, create_prompts=True)
+            self.val_dataset = self.train_dataset  # src/data.py:245-251: identical datasets
+            self.prompt_imgs = self.train_dataset.prompt_imgs
+        if stage == "predict":
+            self.predict_dataset = BeachSegDataset(imgs, None, self.crops, self.config)
+
+    def _loader(self, ds, batch_size, shuffle):
+        return torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=0)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, self.config.batch_size, True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_dataset, self.config.batch_size, False)
+
+    def predict_dataloader(self):
+        return self._loader(self.predict_dataset, 1, False)  # src/data.py:287-293

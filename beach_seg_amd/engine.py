@@ -22,6 +22,21 @@ from . import ops
 from .seggpt import SegGptNative
 
 
+def reduce_prompt_grads(flat: torch.Tensor, process_group=None) -> None:
+    """The ONE data-path collective of a training step: sum over ranks of [P x n gradient rows | P touched flags].
+    `nccl` (= RCCL over xGMI) on GPUs; `gloo` in the CPU tests."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+
+
+def shard_batch(global_batch: int, rank: int, world: int) -> range:
+    """Contiguous slice of the global batch owned by `rank` (SURVEY.md section 8 e)."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return range(rank * per, (rank + 1) * per)
+
+
 class PromptTrainEngine:
     def __init__(self, model: SegGptNative, prompt_images: torch.Tensor, lr: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 1e-2, loss_beta: float = 0.01,
@@ -57,8 +72,7 @@ class PromptTrainEngine:
         gpix = m._run_backward(gpred, B)
         ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
         self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
-        if self.world > 1:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.pg)  # RCCL over xGMI
+        reduce_prompt_grads(self._flat, self.pg)  # RCCL over xGMI when world > 1
         touched = (self._touched_f > 0).to(torch.uint8)
         self.steps += touched.long()
         ops.adamw_step(self.params.view(self.params.shape[0], -1), self.grads.view(self.params.shape[0], -1),

@@ -1,0 +1,62 @@
+"""Predict loop of `/root/reference/src/predict.py:232-262` with the vote mosaic kept on the GPU.
+
+`Accumulator.update` (`:120-159`) = clip the crop window to the mosaic and add a one-hot vote into uint8
+counters; `save_current` (`:100`) = arg-max over classes.  Here the nearest-neighbour down-size of the decoded
+mask (`:259`), the one-hot (`:260`) and the paste run as one HIP kernel per batch of crops, the arg-max as another;
+PNG / GeoTIFF export (`:93-112`) is out of scope.  Integer semantics (uint8 wrap at 256 votes, first-index
+arg-max) match the numpy reference bit for bit (`tests/test_gpu_parity.py::test_predict_vote_glue_bit_exact`).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .model import PromptModel
+
+
+class Accumulator:
+    def __init__(self, out_shape: tuple[int, int], classes: tuple[str, ...], device):
+        self.out_shape, self.num_classes, self.classes, self.device = out_shape, len(classes), classes, device
+        self.current_date = None
+        self.current_pred_counter = None
+
+    def initialize_current(self, date: str) -> None:
+        self.current_date = date
+        self.current_pred_counter = torch.zeros((*self.out_shape, self.num_classes), dtype=torch.uint8, device=self.device)
+
+    def update(self, date: str, crops: torch.Tensor, masks: torch.Tensor, crop_size: int) -> None:
+        """crops i32 (n,4) (xmin,ymin,xmax,ymax); masks u8 (n,hin,win) decoded at network resolution."""
+        if date != self.current_date:
+            self.initialize_current(date)
+        # votes are plain uint8 read-modify-writes: windows that overlap go in separate launches
+        for group in _non_overlapping_groups(crops):
+            ops.vote_paste(self.current_pred_counter, masks[group], crops[group].to(self.device), crop_size)
+
+    def result(self) -> torch.Tensor:
+        return ops.vote_argmax(self.current_pred_counter)
+
+
+def _non_overlapping_groups(crops: torch.Tensor) -> list[torch.Tensor]:
+    boxes = crops.cpu().tolist()
+    groups: list[list[int]] = []
+    for i, (x0, y0, x1, y1) in enumerate(boxes):
+        for g in groups:
+            if all(x1 <= boxes[j][0] or boxes[j][2] <= x0 or y1 <= boxes[j][1] or boxes[j][3] <= y0 for j in g):
+                g.append(i)
+                break
+        else:
+            groups.append([i])
+    return [torch.tensor(g, dtype=torch.long, device=crops.device) for g in groups]
+
+
+@torch.no_grad()
+def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Tensor, crops: torch.Tensor,
+                   out_shape: tuple[int, int], crop_size: int, batch_size: int = 64, date: str = "d0") -> torch.Tensor:
+    """Sliding-window inference (BASELINE config 4): images f32 (n,3,S,S) normalised, one prompt per crop_idx.
+    Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`)."""
+    acc = Accumulator(out_shape, model.conf.classes, model.device)
+    for s in range(0, images.shape[0], batch_size):
+        sl = slice(s, s + batch_size)
+        pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
+        acc.update(date, crops[sl], pred.to(torch.uint8), crop_size)
+    return acc.result()

@@ -1,0 +1,130 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU): config surface, palette / mask
+colouring vs the reference-generated vectors, LR schedule vs torch's own schedulers, dataset dictionary, and the
+N > 1 data-parallel reduction under gloo with world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from beach_seg_amd import ml_util
+from beach_seg_amd.config import CLASSES, BeachSegConfig
+from beach_seg_amd.data import BeachSegDataModule, padded_crop, tif_image
+from beach_seg_amd.engine import reduce_prompt_grads, shard_batch
+from beach_seg_amd.model import MulticlassF1, lr_at_epoch
+
+
+def test_config_surface_matches_reference_fields():
+    c = BeachSegConfig()
+    assert c.classes == CLASSES == ("nodata", "sand", "water", "veg")
+    assert (c.crop_size, c.inpt_size, c.loss_beta, c.lr, c.optimizer, c.scheduler) == (112, 448, 0.01, 1e-3, "adamw", "cosine")
+    c2 = BeachSegConfig.from_dotlist(["batch_size=4", "lr=0.01", "precision=bf16-true", "scale=(0.5,1.0)", "debug=true"])
+    assert (c2.batch_size, c2.lr, c2.precision, c2.scale, c2.debug) == (4, 0.01, "bf16-true", (0.5, 1.0), True)
+    with pytest.raises(KeyError):
+        BeachSegConfig.from_dotlist(["no_such_key=1"])
+
+
+def test_palette_and_mask_colouring_vs_reference(golden_dir):
+    rec = np.load(golden_dir / "wrapper.npz")
+    assert np.array_equal(np.array(ml_util.build_palette(3)), rec["build_palette_3"])
+    assert np.array_equal(np.array(ml_util.build_palette(7)), rec["build_palette_7"])
+    pal = torch.from_numpy(rec["rand_palette_seed42"])
+    assert np.array_equal(ml_util.torch_apply_mask_rgb(pal, torch.from_numpy(rec["mask"])).numpy(), rec["apply_mask_rgb"])
+    torch.manual_seed(42)  # the reference draws from the global RNG (src/util/ml_util.py:102-108)
+    assert np.array_equal(ml_util.generate_random_rgb_palette(4, 3, "cpu").numpy(), rec["rand_palette_seed42"])
+    x = torch.rand(2, 3, 4, 4)
+    assert torch.allclose(ml_util.denormalize(ml_util.normalize(x)), x, atol=1e-6)
+
+
+@pytest.mark.parametrize("warmup,epochs", [(0, 5), (2, 6)])
+def test_lr_schedule_matches_torch_sequential_lr(warmup, epochs):
+    """`configure_optimizers` (src/model.py:385-428) rebuilt with torch's own schedulers vs the closed form."""
+    c = BeachSegConfig(batch_size=4, world_size=2, warmup_epochs=warmup, epochs=epochs)
+    ratio = (4 * 2 / 1) ** 0.5
+    lr, init_lr, min_lr = c.lr * ratio, c.init_lr * ratio, c.min_lr * ratio
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=lr)
+    scheds, miles = [], []
+    if warmup:
+        scheds.append(torch.optim.lr_scheduler.LambdaLR(opt, [lambda e: ((lr - init_lr) * (e / warmup) + init_lr) / lr]))
+        miles.append(warmup)
+    scheds.append(torch.optim.lr_scheduler.CosineAnnealingLR(opt, epochs, min_lr))
+    sched = torch.optim.lr_scheduler.SequentialLR(opt, scheds, miles)
+    for e in range(epochs + warmup):
+        assert abs(opt.param_groups[0]["lr"] - lr_at_epoch(c, e)) < 1e-9, e
+        opt.step()
+        sched.step()
+
+
+def test_tile_front_end_and_dataset_dict():
+    rng = np.random.default_rng(0)
+    bands = rng.integers(200, 3200, size=(4, 64, 64), dtype=np.uint16)
+    rgb = tif_image(bands)
+    assert rgb.shape == (64, 64, 3) and rgb.dtype == np.uint8 and rgb.max() == 255
+    c = padded_crop(np.arange(16).reshape(4, 4), (-1, 2, 3, 6), fill=99)
+    assert c.shape == (4, 4) and c[0, 0] == 99 and c[0, 1] == 8 and c[2, 0] == 99 and c[1, 3] == 14
+    conf = BeachSegConfig(crop_size=112, inpt_size=448)
+    dm = BeachSegDataModule(conf)
+    dm.setup("fit")
+    item = dm.train_dataset[0]
+    assert set(item) == {"crop_idx", "date", "image", "mask", "nodata"}  # src/data.py:118-124
+    assert item["image"].shape == (3, 448, 448) and item["image"].dtype == np.float32
+    assert 0.0 <= item["image"].min() and item["image"].max() <= 1.0
+    assert item["mask"].shape == (448, 448) and item["mask"].dtype == np.uint8 and item["nodata"].dtype == bool
+    assert len(dm.prompt_imgs) == len(dm.train_dataset)  # every train crop is a prompt (src/data.py:74-76)
+
+
+def test_f1_counts():
+    m = MulticlassF1(4, ignore_index=0)
+    m.update(torch.tensor([1, 2, 2, 3, 1]), torch.tensor([1, 2, 3, 3, 0]))
+    assert m.tp.tolist() == [0, 1, 1, 1] and m.fp.tolist() == [0, 0, 1, 0] and m.fn.tolist() == [0, 0, 0, 1]
+    assert abs(m.compute() - (1.0 + 2 / 3 + 2 / 3) / 3) < 1e-9
+
+
+def test_shard_batch():
+    assert list(shard_batch(8, 1, 4)) == [2, 3]
+    with pytest.raises(ValueError):
+        shard_batch(10, 0, 4)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P, n = 5, 7
+    flat = torch.zeros(P * n + P)
+    rows = [0, 3] if rank == 0 else [3, 4]  # rank-local prompts touched this step
+    for r in rows:
+        flat[r * n:(r + 1) * n] += (rank + 1) * (r + 1)
+        flat[P * n + r] = 1.0
+    reduce_prompt_grads(flat)
+    q.put((rank, flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_reduction_gloo_world2():
+    """N = 2 ranks, gloo on CPU: every rank ends with the SUM of the dense prompt-gradient rows and the union of
+    the touched flags -- the one collective of the training step (engine.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    P, n = 5, 7
+    want = torch.zeros(P * n + P)
+    want[0:n] = 1 * 1
+    want[3 * n:4 * n] = 1 * 4 + 2 * 4
+    want[4 * n:5 * n] = 2 * 5
+    want[P * n + 0], want[P * n + 3], want[P * n + 4] = 1, 2, 1
+    assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
