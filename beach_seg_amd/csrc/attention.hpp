@@ -502,3 +502,97 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       }
   }
 }
+
+
+// --------------------------------------------------------------------------------- decomposed rel-pos tables
+// relh[q][kh] = q . rel_pos_h[qh - kh + Hp - 1] / scale,  relw[q][kw] = q . rel_pos_w[qw - kw + Wp - 1] / scale
+// (unscaled q, HF:268-311, HF:326-329) for one grid row of queries per wave, on MFMA, straight into the layouts
+// the attention kernels read.  S^T orientation (lane = query slot): for a fixed grid row the 56 needed rows of
+// rel_pos_h are ONE contiguous (reversed) window, so the h-part is a plain product; the w-part is Toeplitz in
+// (qw, kw), so G_w[q][rel] goes through a 32 x 65 LDS image and is read back sheared.
+struct RelTabArgs {
+  const void* q;  // T [S*N][ld], head h at columns h*64
+  long ld;
+  const void* rel_cat;  // T [>= 2hp-1 + 2wp-1][64]: rel_pos_h rows then rel_pos_w rows
+  float* relh;   // [S][nh][N][hp]
+  float* relw;   // [S][nh][N][32]
+  float* relhT;  // [S][nh][hp][hp*32] or null
+  float* relwT;  // [S][nh][32][hp*32] or null
+  int S, nh, N, hp, wp;
+  float alpha;  // 1 / scale
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  __shared__ float gw[4][32 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int qh = blockIdx.x * 4 + wave;
+  if (qh >= a.hp) return;  // whole wave; no block-level barrier below
+  const long sh = (long)s * a.nh + head;
+  const int npad = a.hp * 32, nrh = 2 * a.hp - 1, nrw = 2 * a.wp - 1;
+  const bool qvalid = col < a.wp;
+  const long q = (long)qh * a.wp + (qvalid ? col : a.wp - 1);
+  Chunk qf[C::KS_D];
+  {
+    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+  }
+  const char* rc = (const char*)a.rel_cat;
+  // ---- h part: rows kh, window row = qh + hp-1 - kh
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    if (blk * 32 >= a.hp) break;
+    const int kh_l = blk * 32 + col;
+    const int rr = kh_l < a.hp ? qh + a.hp - 1 - kh_l : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks)
+      mma32(acc, *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + (2 * ks + h) * 16), qf[ks]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kh0 = blk * 32 + 8 * i + 4 * h;
+      if (kh0 < a.hp) {
+        const f32x4 v = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]} * a.alpha;
+        if (qvalid) *(f32x4*)(a.relh + (sh * a.N + q) * a.hp + kh0) = v;
+        if (a.relhT) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a.relhT[(sh * a.hp + kh0 + j) * npad + qh * 32 + col] = v[j];
+        }
+      }
+    }
+  }
+  // ---- w part: G_w^T[rel][q] -> LDS image [q slot][rel] (stride 65) -> sheared reads
+  float* g = gw[wave];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    if (blk * 32 >= nrw) break;
+    const int rel_l = blk * 32 + col;
+    const int rr = nrh + (rel_l < nrw ? rel_l : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks)
+      mma32(acc, *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + (2 * ks + h) * 16), qf[ks]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[col * 65 + blk * 32 + acc32_row(r, h)] = acc[r] * a.alpha;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done (single-wave image)
+  __builtin_amdgcn_wave_barrier();
+  // relw[q][kw]: lane = kw, 16 queries per half-wave -> 128-byte coalesced rows
+  for (int j = 0; j < 16; ++j) {
+    const int qs = h * 16 + j;
+    if (qs < a.wp && col < a.wp) a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = g[qs * 65 + qs + a.wp - 1 - col];
+  }
+  if (a.relwT) {  // relwT[kw][q slot]: lane = q slot
+    for (int kw = h; kw < a.wp; kw += 2)
+      a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] = qvalid ? g[col * 65 + col + a.wp - 1 - kw] : 0.f;
+  }
+}

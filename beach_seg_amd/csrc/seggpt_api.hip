@@ -221,10 +221,10 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     }
     {
       {
-        GemmArgs g{};
-        g.A = qkv; g.W = m->lw(l, 18); g.M = rows; g.N = m->relcat_rows; g.K = 64; g.lda = 3 * D; g.tokens = N; g.wp = wp;
-        g.hp = hp; g.nh = nh; g.alpha = 1.0f / scale; g.out = relh; g.out2 = relw;
-        gemm<T, A_PLAIN, EPI_RELPOS>(m, g, st);
+        RelTabArgs r{};
+        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relh = relh; r.relw = relw; r.S = S; r.nh = nh; r.N = N;
+        r.hp = hp; r.wp = wp; r.alpha = 1.0f / scale;
+        hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, S), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
@@ -401,10 +401,10 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
                          B, N, hp, wp, nh);
       CHECK_LAUNCH();
       {
-        GemmArgs g{};
-        g.A = qkv; g.W = m->lw(l, 18); g.M = rows; g.N = m->relcat_rows; g.K = 64; g.lda = 3 * D; g.tokens = N; g.wp = wp;
-        g.hp = hp; g.nh = nh; g.alpha = 1.0f / scale; g.out = relh; g.out2 = relw; g.out3 = relhT; g.out4 = relwT;
-        gemm<T, A_PLAIN, EPI_RELPOS>(m, g, st);
+        RelTabArgs r{};
+        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relh = relh; r.relw = relw; r.relhT = relhT; r.relwT = relwT;
+        r.S = B; r.nh = nh; r.N = N; r.hp = hp; r.wp = wp; r.alpha = 1.0f / scale;
+        hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
       hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh);
@@ -478,7 +478,7 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   if (c.hidden_size % 64 || c.mlp_dim % 64 || c.hidden_size > 2048) return fail("hidden_size / mlp_dim must be multiples of 64, hidden <= 2048");
   if (c.canvas_h % 32 || c.canvas_w % 32) return fail("canvas must be a multiple of 32 pixels in both axes");
   const int hp = c.canvas_h / 16, wp = c.canvas_w / 16;
-  if (wp > 32) return fail("token-grid width %d > 32 not supported", wp);
+  if (wp > 32 || hp > 64) return fail("token grid %d x %d exceeds 64 x 32", hp, wp);
   if (c.num_taps < 1 || c.num_taps > BSG_MAX_TAPS) return fail("num_taps out of range");
   for (int i = 0; i < c.num_taps; ++i)
     if (c.taps[i] < c.merge_index || c.taps[i] >= c.num_layers) return fail("tap index %d out of range", c.taps[i]);
