@@ -169,25 +169,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (acc32_row(r, h) >= a.wp) st[b][r] = -INFINITY;
+        if (8 * (r >> 2) + 8 > a.wp)  // only register groups that can hold padded slots (scalar test)
+          if (acc32_row(r, h) >= a.wp) st[b][r] = -INFINITY;
         mx = fmaxf(mx, st[b][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
-    m = mn;
+    if (__builtin_amdgcn_ballot_w64(mn > m)) {  // wave-uniform: skip the O rescale once the running max is stable
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      m = mn;
+    }
+    const float nmc = -m * c2;
     float ps = 0.f;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f((st[b][r] - mn) * c2);
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[b][r], c2, nmc));
         st[b][r] = p;
         ps += p;
       }
-    l = l * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    l += ps;
     // O^T[d][q] += V^T[d][slot] P^T[slot][q]
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool ok = acc32_row(r, h) < a.wp;
-        const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lse) : 0.f;
+        const bool ok = (8 * (r >> 2) + 8 <= a.wp) || acc32_row(r, h) < a.wp;
+        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse)) : 0.f;
         const float ds = ok ? p * (dp[r] - dl) : 0.f;
         st[r] = ds;
         drw[r] += ds;
@@ -469,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool ok = key_valid && acc32_row(r, h) < a.wp;
-        const float p = ok ? __builtin_amdgcn_exp2f(st[r] * c2 - lse4[r >> 2][r & 3]) : 0.f;
+        const bool ok = key_valid && ((8 * (r >> 2) + 8 <= a.wp) || acc32_row(r, h) < a.wp);
+        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse4[r >> 2][r & 3])) : 0.f;
         st[r] = p;                                               // P
         dp[r] = ok ? p * (dp[r] - dl4[r >> 2][r & 3]) : 0.f;      // dS
       }
