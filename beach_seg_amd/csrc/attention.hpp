@@ -169,9 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (8 * (r >> 2) + 8 > a.wp)  // only register groups that can hold padded slots (scalar test)
-          if (acc32_row(r, h) >= a.wp) st[b][r] = -INFINITY;
-        mx = fmaxf(mx, st[b][r]);
+        mx = fmaxf(mx, st[b][r]);  // padded key slots carry relw = -inf, so they are -inf here
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
@@ -309,9 +307,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool ok = (8 * (r >> 2) + 8 <= a.wp) || acc32_row(r, h) < a.wp;
-        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse)) : 0.f;
-        const float ds = ok ? p * (dp[r] - dl) : 0.f;
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse));  // 0 on padded key slots (bias -inf)
+        const float ds = p * (dp[r] - dl);
         st[r] = ds;
         drw[r] += ds;
         sum += ds;
@@ -474,10 +471,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const bool ok = key_valid && ((8 * (r >> 2) + 8 <= a.wp) || acc32_row(r, h) < a.wp);
-        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse4[r >> 2][r & 3])) : 0.f;
-        st[r] = p;                                               // P
-        dp[r] = ok ? p * (dp[r] - dl4[r >> 2][r & 3]) : 0.f;      // dS
+        // padded key lanes / padded query slots carry relwT = -inf: P = 0 there without any masking
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse4[r >> 2][r & 3]));
+        st[r] = p;                                   // P
+        dp[r] = p * (dp[r] - dl4[r >> 2][r & 3]);     // dS
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) {
@@ -592,12 +589,15 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done (single-wave image)
   __builtin_amdgcn_wave_barrier();
   // relw[q][kw]: lane = kw, 16 queries per half-wave -> 128-byte coalesced rows
+  // padded key slots (kw >= wp) and padded query slots get -inf: the attention kernels need no masking
   for (int j = 0; j < 16; ++j) {
     const int qs = h * 16 + j;
-    if (qs < a.wp && col < a.wp) a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = g[qs * 65 + qs + a.wp - 1 - col];
+    if (qs < a.wp)
+      a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = col < a.wp ? g[qs * 65 + qs + a.wp - 1 - col] : -INFINITY;
   }
   if (a.relwT) {  // relwT[kw][q slot]: lane = q slot
-    for (int kw = h; kw < a.wp; kw += 2)
-      a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] = qvalid ? g[col * 65 + col + a.wp - 1 - kw] : 0.f;
+    for (int kw = h; kw < 32; kw += 2)
+      a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] =
+          (qvalid && kw < a.wp) ? g[col * 65 + col + a.wp - 1 - min(kw, a.wp - 1)] : -INFINITY;
   }
 }
