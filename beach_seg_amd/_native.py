@@ -12,7 +12,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "libbsg_hip.so"
 _lib = None
 
 BSG_DTYPE_F32, BSG_DTYPE_BF16 = 0, 1
-BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 19
+BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 20
 
 # every exported symbol of include/beach_seg_amd.h (tests check the library exports exactly these)
 SYMBOLS = (

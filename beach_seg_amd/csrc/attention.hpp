@@ -515,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 struct RelTabArgs {
   const void* q;  // T [S*N][ld], head h at columns h*64
   long ld;
-  const void* rel_cat;  // T [>= 2hp-1 + 2wp-1][64]: rel_pos_h rows then rel_pos_w rows
+  const void* rel_cat;  // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2hp).., zeros elsewhere
   float* relh;   // [S][nh][N][hp]
   float* relw;   // [S][nh][N][32]
   float* relhT;  // [S][nh][hp][hp*32] or null
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
   const int qh = blockIdx.x * 4 + wave;
   if (qh >= a.hp) return;  // whole wave; no block-level barrier below
   const long sh = (long)s * a.nh + head;
-  const int npad = a.hp * 32, nrh = 2 * a.hp - 1, nrw = 2 * a.wp - 1;
+  const int npad = a.hp * 32, nrh = (2 * a.hp + 15) & ~15, nrw = 2 * a.wp - 1;  // rel_pos_w rows start at nrh
   const bool qvalid = col < a.wp;
   const long q = (long)qh * a.wp + (qvalid ? col : a.wp - 1);
   Chunk qf[C::KS_D];
@@ -599,5 +599,71 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
     for (int kw = h; kw < 32; kw += 2)
       a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] =
           (qvalid && kw < a.wp) ? g[col * 65 + col + a.wp - 1 - min(kw, a.wp - 1)] : -INFINITY;
+  }
+}
+
+
+// ------------------------------------------------------------------------ rel-pos gradient into dq (MFMA)
+// dq[q][c] += sum_kh drelh[q][kh] rel_pos_h[qh+Hp-1-kh][c] + sum_kw drelw[q][kw] rel_pos_w[qw+Wp-1-kw][c]
+// One wave per grid row of queries; the contraction runs over the REL index r (so the A operand is the
+// transposed table rel_catT[c][r], read in aligned chunks) and the B operand X[r][q] = drel[q][q_pos + size-1 - r]
+// is gathered per lane with bounds predicates.
+struct RelBwdArgs {
+  void* dq;  // T [S*N][ld], head h at columns h*64 (read-modify-write)
+  long ld;
+  const void* rel_catT;  // T [64][LH + LW]
+  const float* drelh;    // [S][nh][N][hp]
+  const float* drelw;    // [S][nh][N][32]
+  int S, nh, N, hp, wp;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  constexpr int EPC = Traits<T>::EPC;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int qh = blockIdx.x * 4 + wave;
+  if (qh >= a.hp) return;
+  const long sh = (long)s * a.nh + head;
+  const int LH = (2 * a.hp + 15) & ~15, LW = (2 * a.wp + 15) & ~15, RC = LH + LW;
+  const bool qvalid = col < a.wp;
+  const long q = (long)qh * a.wp + (qvalid ? col : a.wp - 1);
+  const float* dh = a.drelh + (sh * a.N + q) * a.hp;
+  const float* dw = a.drelw + (sh * a.N + q) * 32;
+  const char* rt = (const char*)a.rel_catT;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  for (int part = 0; part < 2; ++part) {
+    const int len = part == 0 ? LH : LW, size = part == 0 ? a.hp : a.wp, pos = part == 0 ? qh : col;
+    const float* src = part == 0 ? dh : dw;
+    const int cbase = part == 0 ? 0 : LH;
+    for (int ks = 0; ks < len / (2 * EPC); ++ks) {
+      const int r0 = (2 * ks + h) * EPC;
+      Chunk b;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        const int k = pos + size - 1 - (r0 + j);
+        const float v = (qvalid && k >= 0 && k < size) ? src[k] : 0.f;
+        b[j] = from_f32<T>(v);
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+        mma32(acc[blk], *(const Chunk*)(rt + ((long)(32 * blk + col) * RC + cbase + r0) * sizeof(T)), b);
+    }
+  }
+  if (qvalid) {
+    T* row = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        typename Traits<T>::Vec4* p = (typename Traits<T>::Vec4*)(row + 32 * blk + 8 * i + 4 * h);
+        const typename Traits<T>::Vec4 o = *p;
+        *p = pack4<T>(to_f32(o[0]) + acc[blk][4 * i], to_f32(o[1]) + acc[blk][4 * i + 1],
+                      to_f32(o[2]) + acc[blk][4 * i + 2], to_f32(o[3]) + acc[blk][4 * i + 3]);
+      }
   }
 }

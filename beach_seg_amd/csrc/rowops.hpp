@@ -234,21 +234,38 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(T* __restrict__ dq, lon
 }
 
 // ------------------------------------------------------------------------------------- head transposes
-// X [S*N][ld] (head columns) -> XT [S][nh][64][Hp*32]; one block per (grid row, head, stream); padded slots = 0
+// X [S*N][ld] (head columns) -> XT [S][nh][64][Hp*32]; one block per (grid row, group of hb <= 4 heads, stream);
+// 16-byte loads of the contiguous hb*64-element row segments, 16-byte stores of 8 slots; padded slots = 0.
 template <typename T>
 __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict__ x, long ld, T* __restrict__ xt,
-                                                              int N, int hp, int wp, int nh) {
-  __shared__ float tile[32][65];
-  const int gr = blockIdx.x, head = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
-  for (int i = tid; i < 32 * 64; i += 256) {
-    const int kw = i >> 6, d = i & 63;
-    tile[kw][d] = kw < wp ? to_f32(x[((long)s * N + gr * wp + kw) * ld + head * 64 + d]) : 0.f;
+                                                              int N, int hp, int wp, int nh, int hb) {
+  constexpr int EPC = Traits<T>::EPC;
+  typedef typename Traits<T>::Chunk Chunk;
+  __shared__ float tile[32][257];
+  const int gr = blockIdx.x, head0 = blockIdx.y * hb, s = blockIdx.z, tid = threadIdx.x;
+  const int cpt = hb * 64 / EPC;  // 16-byte chunks per token segment
+  for (int i = tid; i < 32 * cpt; i += 256) {
+    const int kw = i / cpt, c = i % cpt;
+    float v[EPC];
+    if (kw < wp) {
+      const Chunk ch = *(const Chunk*)(x + ((long)s * N + gr * wp + kw) * ld + head0 * 64 + c * EPC);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) v[j] = to_f32(ch[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) tile[kw][c * EPC + j] = v[j];
   }
   __syncthreads();
-  const int d = tid >> 2, k0 = (tid & 3) * 8;
-  T* dst = xt + (((long)s * nh + head) * 64 + d) * (hp * 32) + gr * 32 + k0;
-  *(typename Traits<T>::Vec4*)dst = pack4<T>(tile[k0][d], tile[k0 + 1][d], tile[k0 + 2][d], tile[k0 + 3][d]);
-  *(typename Traits<T>::Vec4*)(dst + 4) = pack4<T>(tile[k0 + 4][d], tile[k0 + 5][d], tile[k0 + 6][d], tile[k0 + 7][d]);
+  for (int i = tid; i < hb * 64 * 4; i += 256) {
+    const int g = i & 3, hd = i >> 2;  // hd = head_local*64 + d
+    T* dst = xt + (((long)s * nh + head0 + (hd >> 6)) * 64 + (hd & 63)) * (hp * 32) + gr * 32 + 8 * g;
+    *(typename Traits<T>::Vec4*)dst = pack4<T>(tile[8 * g][hd], tile[8 * g + 1][hd], tile[8 * g + 2][hd], tile[8 * g + 3][hd]);
+    *(typename Traits<T>::Vec4*)(dst + 4) =
+        pack4<T>(tile[8 * g + 4][hd], tile[8 * g + 5][hd], tile[8 * g + 6][hd], tile[8 * g + 7][hd]);
+  }
 }
 
 // delta[sh][qpad] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one wave per token row

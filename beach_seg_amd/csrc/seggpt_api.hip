@@ -227,8 +227,9 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
         hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, S), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
-                         wp, nh);
+      const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
+                         wp, nh, hb);
       CHECK_LAUNCH();
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o; a.ldo = D;
@@ -407,10 +408,11 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
-                         nh);
+      const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh, hb);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh, hb);
+      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
+                         nh, hb);
       CHECK_LAUNCH();
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.relh = relh;
@@ -423,13 +425,13 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3((N + 127) / 128, nh, B), dim3(256), 6 * AttnK<T>::TILE, st, a);
       }
       CHECK_LAUNCH();
-      const int lds2 = (2 * hp - 1 + 2 * wp - 1) * 64 * 4;
-      static bool once3 = (allow_lds(relpos_bwd_kernel<T>, 160 * 1024), true);
-      (void)once3;
-      hipLaunchKernelGGL((relpos_bwd_kernel<T>), dim3((N + 63) / 64, nh, B), dim3(256), lds2, st, dqkv, (long)3 * D,
-                         (const float*)m->lw(l, 16), (const float*)m->lw(l, 17), (const float*)drelh, (const float*)drelw, N,
-                         hp, wp, nh);
-      CHECK_LAUNCH();
+      {
+        RelBwdArgs rb{};
+        rb.dq = dqkv; rb.ld = 3 * D; rb.rel_catT = m->lw(l, 19); rb.drelh = drelh; rb.drelw = drelw; rb.S = B; rb.nh = nh;
+        rb.N = N; rb.hp = hp; rb.wp = wp;
+        hipLaunchKernelGGL((relpos_bwd_mfma_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, rb);
+        CHECK_LAUNCH();
+      }
       AttnBwdKvArgs k{};
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;

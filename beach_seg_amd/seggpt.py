@@ -65,10 +65,15 @@ def token_tables(sd: dict, g: SegGptGeometry) -> tuple[torch.Tensor, torch.Tenso
 
 
 def _rel_cat(rel_h: torch.Tensor, rel_w: torch.Tensor) -> torch.Tensor:
-    """[rel_pos_h; rel_pos_w] padded with zero rows to a multiple of 4 rows (operand of the rel-pos table GEMM)."""
-    cat = torch.cat([rel_h.detach().float(), rel_w.detach().float()], 0)
-    pad = (-cat.shape[0]) % 4
-    return torch.cat([cat, cat.new_zeros(pad, cat.shape[1])], 0) if pad else cat
+    """[LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH.., zeros elsewhere (LH/LW = 2Hp / 2Wp rounded up
+    to 16): operand of the rel-pos table kernel; its transpose feeds the rel-pos gradient kernel."""
+    rel_h, rel_w = rel_h.detach().float(), rel_w.detach().float()
+    LH = (rel_h.shape[0] + 1 + 15) // 16 * 16
+    LW = (rel_w.shape[0] + 1 + 15) // 16 * 16
+    cat = rel_h.new_zeros(LH + LW, rel_h.shape[1])
+    cat[: rel_h.shape[0]] = rel_h
+    cat[LH: LH + rel_w.shape[0]] = rel_w
+    return cat
 
 
 def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) -> list[torch.Tensor]:
@@ -119,6 +124,7 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) 
             w1, w1T, f32(sd[l + "mlp.lin1.bias"]), w2, w2T, f32(sd[l + "mlp.lin2.bias"]),
             f32(sd[l + "attention.rel_pos_h"]), f32(sd[l + "attention.rel_pos_w"]),
             T(_rel_cat(sd[l + "attention.rel_pos_h"], sd[l + "attention.rel_pos_w"])),
+            T(_rel_cat(sd[l + "attention.rel_pos_h"], sd[l + "attention.rel_pos_w"]).t()),
         ]
     return table
 

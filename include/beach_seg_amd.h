@@ -27,7 +27,7 @@ extern "C" {
 #define BSG_DTYPE_BF16 1 /* throughput mode: bf16 storage / bf16 MFMA, fp32 accumulate + fp32 residual stream */
 #define BSG_MAX_TAPS 8
 #define BSG_GLOBAL_WEIGHTS 16 /* weight-table slots before the per-layer blocks */
-#define BSG_LAYER_WEIGHTS 19  /* slots per encoder layer */
+#define BSG_LAYER_WEIGHTS 20  /* slots per encoder layer */
 
 /* Mirror of the SegGptConfig fields the path reads (HF:configuration_seggpt.py:57-75). */
 typedef struct bsg_config {
@@ -48,9 +48,10 @@ typedef struct bsg_model bsg_model;
  *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*64][taps*D]
  *         7 dec_wT T[taps*D][256*64]   8 dec_b f32   9 conv_w T[64 co][9][64 ci]   10 conv_wT T[64 ci][9][64 co]
  *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][64]   15 head_b f32[3]
- * layer l at 16 + 19*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
+ * layer l at 16 + 20*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
  *         10 fc1_w 11 fc1_wT 12 fc1_b 13 fc2_w 14 fc2_wT 15 fc2_b 16 rel_pos_h f32[2Hp-1][64] 17 rel_pos_w f32
- *         18 rel_cat T[roundup4(2Hp-1 + 2Wp-1)][64] = [rel_pos_h; rel_pos_w; zero rows]
+ *         18 rel_cat T[LH + LW][64], LH = roundup16(2Hp), LW = roundup16(2Wp): rel_pos_h rows at 0, rel_pos_w rows
+ *         at LH, zero rows elsewhere   19 rel_catT T[64][LH + LW] (its transpose)
  * tok_table[kind][t] folds conv bias (or mask_token for masked tokens of the mask stream), segment token,
  * bicubic-resized position embedding and type token (HF:163-206): pure constants of the checkpoint. */
 int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights, bsg_model** out);
