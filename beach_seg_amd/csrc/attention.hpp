@@ -621,6 +621,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   constexpr int EPC = Traits<T>::EPC;
+  // per wave: the grid row's drelh block [wp][hp] and drelw block [wp][32] are CONTIGUOUS in HBM: stage them with
+  // 16-byte loads into padded LDS images (row strides hp+1 / 33 floats: conflict-free per-lane gathers)
+  __shared__ float sm[4][32 * 65 + 32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int head = blockIdx.y, s = blockIdx.z;
@@ -629,16 +632,35 @@ __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
   const long sh = (long)s * a.nh + head;
   const int LH = (2 * a.hp + 15) & ~15, LW = (2 * a.wp + 15) & ~15, RC = LH + LW;
   const bool qvalid = col < a.wp;
-  const long q = (long)qh * a.wp + (qvalid ? col : a.wp - 1);
-  const float* dh = a.drelh + (sh * a.N + q) * a.hp;
-  const float* dw = a.drelw + (sh * a.N + q) * 32;
+  const long q0 = (long)qh * a.wp;
+  float* lh = sm[wave];
+  float* lw = lh + 32 * 65;
+  {
+    const float* gh = a.drelh + (sh * a.N + q0) * a.hp;  // wp * hp floats
+    const int nh4 = a.wp * a.hp / 4;
+    for (int i = lane; i < nh4; i += 64) {
+      const f32x4 v = *(const f32x4*)(gh + 4 * i);
+      const int e = 4 * i, r = e / a.hp, c = e % a.hp;  // hp % 4 == 0: a chunk never straddles rows
+      float* d = lh + r * (a.hp + 1) + c;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    const float* gw = a.drelw + (sh * a.N + q0) * 32;  // wp * 32 floats
+    for (int i = lane; i < a.wp * 8; i += 64) {
+      const f32x4 v = *(const f32x4*)(gw + 4 * i);
+      float* d = lw + (i >> 3) * 33 + 4 * (i & 7);
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
   const char* rt = (const char*)a.rel_catT;
   f32x16 acc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  const int qc = qvalid ? col : 0;
   for (int part = 0; part < 2; ++part) {
     const int len = part == 0 ? LH : LW, size = part == 0 ? a.hp : a.wp, pos = part == 0 ? qh : col;
-    const float* src = part == 0 ? dh : dw;
+    const float* src = part == 0 ? lh + qc * (a.hp + 1) : lw + qc * 33;
     const int cbase = part == 0 ? 0 : LH;
     for (int ks = 0; ks < len / (2 * EPC); ++ks) {
       const int r0 = (2 * ks + h) * EPC;
@@ -646,8 +668,9 @@ __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
 #pragma unroll
       for (int j = 0; j < EPC; ++j) {
         const int k = pos + size - 1 - (r0 + j);
-        const float v = (qvalid && k >= 0 && k < size) ? src[k] : 0.f;
-        b[j] = from_f32<T>(v);
+        const bool ok = qvalid && k >= 0 && k < size;
+        const float v = src[ok ? k : 0];
+        b[j] = from_f32<T>(ok ? v : 0.f);
       }
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
@@ -655,7 +678,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
     }
   }
   if (qvalid) {
-    T* row = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
+    T* row = (T*)a.dq + ((long)s * a.N + q0 + col) * a.ld + head * 64;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll

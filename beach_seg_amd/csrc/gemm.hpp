@@ -20,6 +20,7 @@ enum EpiMode {
   EPI_PLAIN = 5,      // out[m][n] = T(acc)
   EPI_GELU_BWD = 6,   // out[m][n] = T(acc * gelu'(aux[m][n]))
   EPI_UNPATCH = 7,    // patch-embed dgrad: scatter rows into the (B,3,H/2,W) fp32 prompt-pixel gradient
+  EPI_NONE = 9,       // diagnostics: no stores (accumulators kept alive), to price the epilogue
   EPI_RELPOS = 8,     // per head (blockIdx.y): q . [rel_pos_h; rel_pos_w]^T scattered into the relh / relw tables
 };
 
@@ -63,6 +64,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       const int n = nw + ni * 16 + 4 * fchunk;
       if (n >= g.N) continue;
       f32x4 v = acc[ni][mi];
+      if (EPI == EPI_NONE) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
         const f32x4 b = *(const f32x4*)(g.bias + n);
         v += b;

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from beach_seg_amd import ops
 dev = torch.device("cuda:0")
-shapes = [(100352, 4096, 1024), (100352, 1024, 4096), (100352, 3072, 1024), (100352, 1024, 1024)]
+shapes = [(100352, 4096, 1024), (100352, 1024, 4096), (100352, 3072, 1024), (100352, 1024, 1024), (100352, 1024, 2048), (100352, 1024, 3072), (100352, 4096, 2048), (65536, 1024, 1024), (65536, 4096, 1024)]
 if len(sys.argv) > 3:
     shapes = [tuple(int(x) for x in sys.argv[1:4])]
 for M, N, K in shapes:
