@@ -53,8 +53,76 @@ struct GemmArgs {
 };
 
 // ---- shared epilogue: acc[ni][mi][r] = C[mw + mi*16 + (lane&15)][nw + ni*16 + 4*(lane>>4) + r]
+DEVI unsigned pack_bf16x2(float a, float b) {
+  const bf16x2 v = bf16x2{(bf16_t)a, (bf16_t)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// bf16 outputs, N % 16 == 0: exchange register pairs between the four 16-lane rows (v_permlane16_swap) so every
+// lane owns 8 consecutive columns -> 16-byte stores, 64 contiguous bytes per output row per instruction (the
+// narrow path writes 32-byte segments and doubles the number of memory requests of the tile's store burst).
+template <int EPI>
+DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = mw + mi * 16 + frow;
+    const bool mok = m < g.M;
+    const int mc = mok ? m : g.M - 1;
+    unsigned lo[4], hi[4], lo2[4], hi2[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = min(nw + ni * 16 + 4 * fchunk, g.N - 4);
+      f32x4 v = acc[ni][mi];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT) v += *(const f32x4*)(g.bias + n);
+      if (EPI == EPI_BIAS_GELU) {
+        lo2[ni] = pack_bf16x2(v[0], v[1]);
+        hi2[ni] = pack_bf16x2(v[2], v[3]);
+        v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+      } else if (EPI == EPI_GELU_BWD) {
+        const bf16x4 hp = *(const bf16x4*)((const bf16_t*)g.aux + (long)mc * g.ldaux + n);
+        v = f32x4{v[0] * gelu_grad_f((float)hp[0]), v[1] * gelu_grad_f((float)hp[1]), v[2] * gelu_grad_f((float)hp[2]),
+                  v[3] * gelu_grad_f((float)hp[3])};
+      }
+      lo[ni] = pack_bf16x2(v[0], v[1]);
+      hi[ni] = pack_bf16x2(v[2], v[3]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int ia = 2 * pr, ib = 2 * pr + 1;
+      auto r0 = __builtin_amdgcn_permlane16_swap(lo[ia], lo[ib], false, false);
+      auto r1 = __builtin_amdgcn_permlane16_swap(hi[ia], hi[ib], false, false);
+      const u32x4 out = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      const int col = nw + ((fchunk & 1) ? ib : ia) * 16 + (fchunk >> 1) * 8;
+      const bool ok = mok && col < g.N;
+      long off;
+      if (EPI == EPI_FEAT) {
+        const int b = m / g.tokens, t = m % g.tokens;
+        const int ph = t / g.wp, pw = t % g.wp;
+        const int p1 = col >> 10, p2 = (col >> 6) & 15, c = col & 63;
+        off = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
+      } else {
+        off = (long)m * g.ldo + col;
+      }
+      if (ok) *(u32x4*)((bf16_t*)g.out + off) = out;
+      if (EPI == EPI_BIAS_GELU) {
+        auto q0 = __builtin_amdgcn_permlane16_swap(lo2[ia], lo2[ib], false, false);
+        auto q1 = __builtin_amdgcn_permlane16_swap(hi2[ia], hi2[ib], false, false);
+        if (ok && g.out2) *(u32x4*)((bf16_t*)g.out2 + off) = u32x4{q0[0], q1[0], q0[1], q1[1]};
+      }
+    }
+  }
+}
+
 template <typename T, int EPI>
 DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, int head) {
+  if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
+                                   EPI == EPI_FEAT)) {
+    if (!(g.N & 15)) {
+      gemm_epilogue_wide_bf16<EPI>(g, acc, mw, nw, frow, fchunk);
+      return;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = mw + mi * 16 + frow;
