@@ -113,13 +113,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
   }
-  float rw[16];
+  f32x16 rwv;
   {
     const float* p = a.relw + (sh * a.N + q) * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
-      rw[4 * i] = v[0]; rw[4 * i + 1] = v[1]; rw[4 * i + 2] = v[2]; rw[4 * i + 3] = v[3];
+      rwv[4 * i] = v[0]; rwv[4 * i + 1] = v[1]; rwv[4 * i + 2] = v[2]; rwv[4 * i + 3] = v[3];
     }
   }
   const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
@@ -153,24 +153,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const char* kt_l = smem + buf * 2 * C::TILE;
     const char* vt_l = kt_l + C::TILE;
 
-    // S^T[slot][q] = bias + K q^T       (unscaled; bias pre-divided by scale)
+    // S^T[slot][q] = relw (initial accumulator = the loop-invariant register vector) + K q^T; the per-block
+    // row bias relh[b] is one scalar per lane and is folded into the max and the exponent instead of 32 adds.
     f32x16 st[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[b][r] = rw[r] + rh[b];
+      st[b] = rwv;
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks)
         mma32(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qf[ks]);
     }
-    // online softmax over this lane's 32 slots (+ partner half-wave)
-    float mx = -INFINITY;
+    // online softmax over this lane's 32 slots (+ partner half-wave); padded key slots carry relw = -inf
+    float mx0 = st[0][0], mx1 = st[1][0];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        mx = fmaxf(mx, st[b][r]);  // padded key slots carry relw = -inf, so they are -inf here
-      }
+    for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, st[0][r]); mx1 = fmaxf(mx1, st[1][r]); }
+    float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
     if (__builtin_amdgcn_ballot_w64(mn > m)) {  // wave-uniform: skip the O rescale once the running max is stable
@@ -180,16 +177,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
       m = mn;
     }
-    const float nmc = -m * c2;
+    const float nb0 = (rh[0] - m) * c2, nb1 = (rh[1] - m) * c2;
     float ps = 0.f;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[b][r], c2, nmc));
-        st[b][r] = p;
-        ps += p;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(st[0][r], c2, nb0));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(st[1][r], c2, nb1));
+      st[0][r] = p0;
+      st[1][r] = p1;
+      ps += p0 + p1;
+    }
     l += ps;
     // O^T[d][q] += V^T[d][slot] P^T[slot][q]
 #pragma unroll
@@ -247,13 +244,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       dof[ks] = *(const Chunk*)(drow + (2 * ks + h) * 16);
     }
   }
-  float rw[16], drw[16];
+  f32x16 rwv;
+  float drw[16];
   {
     const float* p = a.relw + (sh * a.N + q) * 32;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
-      rw[4 * i] = v[0]; rw[4 * i + 1] = v[1]; rw[4 * i + 2] = v[2]; rw[4 * i + 3] = v[3];
+      rwv[4 * i] = v[0]; rwv[4 * i + 1] = v[1]; rwv[4 * i + 2] = v[2]; rwv[4 * i + 3] = v[3];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) drw[i] = 0.f;
@@ -296,18 +294,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     float drh[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      f32x16 st, dp;
+      f32x16 st = rwv, dp;  // S^T accumulator starts at relw (column bias)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = rw[r] + rh[b]; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
         mma32(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qf[ks]);
         mma32(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dof[ks]);
       }
+      const float nb = fmaf(rh[b], c2, -lse);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse));  // 0 on padded key slots (bias -inf)
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, nb));  // 0 on padded key slots (bias -inf)
         const float ds = p * (dp[r] - dl);
         st[r] = ds;
         drw[r] += ds;
