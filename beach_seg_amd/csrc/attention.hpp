@@ -62,12 +62,12 @@ template <typename T> DEVI typename Traits<T>::Chunk lds_chunk(const char* tile,
 
 // A-operand chunk of a [row][64 contraction slots] LDS tile matching an S^T-layout accumulator block used as
 // the B operand.  bf16: k-step s (16 slots) of 32-slot block b, element j <-> slot 16s + 8(j>>2) + 4h + (j&3);
-// f32: k-step s (8 slots), element j <-> slot 8s + 4h + j.
+// f32: k-step s (8 slots), element j <-> slot 8s + 4h + j.  In both cases one conflict-free ds_read_b128.
 DEVI bf16x8 lds_perm_chunk(const char* tile, int row, int b, int s, int h, bf16_t) {
-  const int c0 = 4 * b + 2 * s, x = swz<128>(row);
-  const bf16x4 lo = *(const bf16x4*)(tile + row * 128 + ((c0 ^ x) << 4) + 8 * h);
-  const bf16x4 hi = *(const bf16x4*)(tile + row * 128 + (((c0 + 1) ^ x) << 4) + 8 * h);
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  // bf16 "transposed" tensors are stored with every 16-slot group permuted (slot 8a + 4h + i at position
+  // 8h + 4a + i, see head_transpose_kernel), so the 8 slots a lane needs are ONE 16-byte chunk: 4b + 2s + h
+  const int c = 4 * b + 2 * s + h;
+  return *(const bf16x8*)(tile + row * 128 + ((c ^ swz<128>(row)) << 4));
 }
 DEVI f32x4 lds_perm_chunk(const char* tile, int row, int b, int s, int h, float) {
   const int c = 8 * b + 2 * s + h;

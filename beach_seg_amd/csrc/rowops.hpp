@@ -260,11 +260,14 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
   }
   __syncthreads();
   for (int i = tid; i < hb * 64 * 4; i += 256) {
-    const int g = i & 3, hd = i >> 2;  // hd = head_local*64 + d
+    const int g = i & 3, hd = i >> 2;  // hd = head_local*64 + d; g = group of 8 output positions
     T* dst = xt + (((long)s * nh + head0 + (hd >> 6)) * 64 + (hd & 63)) * (hp * 32) + gr * 32 + 8 * g;
-    *(typename Traits<T>::Vec4*)dst = pack4<T>(tile[8 * g][hd], tile[8 * g + 1][hd], tile[8 * g + 2][hd], tile[8 * g + 3][hd]);
-    *(typename Traits<T>::Vec4*)(dst + 4) =
-        pack4<T>(tile[8 * g + 4][hd], tile[8 * g + 5][hd], tile[8 * g + 6][hd], tile[8 * g + 7][hd]);
+    // bf16: every 16-slot group is stored permuted (position 8h + 4a + i holds slot 8a + 4h + i) so that the MFMA
+    // operand matching an S^T accumulator is one aligned 16-byte chunk (attention.hpp, lds_perm_chunk)
+    const int s0 = sizeof(T) == 2 ? 16 * (g >> 1) + 4 * (g & 1) : 8 * g;       // slots of positions 0..3
+    const int s1 = sizeof(T) == 2 ? s0 + 8 : s0 + 4;                           // slots of positions 4..7
+    *(typename Traits<T>::Vec4*)dst = pack4<T>(tile[s0][hd], tile[s0 + 1][hd], tile[s0 + 2][hd], tile[s0 + 3][hd]);
+    *(typename Traits<T>::Vec4*)(dst + 4) = pack4<T>(tile[s1][hd], tile[s1 + 1][hd], tile[s1 + 2][hd], tile[s1 + 3][hd]);
   }
 }
 
