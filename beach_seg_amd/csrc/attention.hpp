@@ -38,6 +38,16 @@ struct AttnArgs {
   float scale;
 };
 
+// 1-D grid -> (x, head, stream) with all x-blocks of one (stream, head) on the SAME XCD: they re-read the same
+// K / V^T (or Q / dO) tiles, which then come from that XCD's L2 instead of eight separate fetches from HBM.
+DEVI void attn_block_ids(int nx, int nh, int S, int& x, int& head, int& s) {
+  const int lid = xcd_remap(blockIdx.x, nx * nh * S);
+  x = lid % nx;
+  const int t = lid / nx;
+  head = t % nh;
+  s = t / nh;
+}
+
 template <int RB> DEVI int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : (row & 15); }
 
 // token index of slot `kw` of grid row `gr` (clamped to a valid token: padded slots carry weight 0)
@@ -98,8 +108,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, s = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int bx, head, s;
+  attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
+  const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const long sh = (long)s * a.nh + head;
   const int npad = a.hp * 32;
@@ -224,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, s = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int bx, head, s;
+  attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
+  const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const int qpad = (q / a.wp) * 32 + (q % a.wp);
   const long sh = (long)s * a.nh + head;
@@ -385,9 +397,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, s = blockIdx.z;
+  int bx, head, s;
+  attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
   const int nt = a.hp >> 1;
-  const int kr0 = blockIdx.x * 8;
+  const int kr0 = bx * 8;
   const bool wave_valid = kr0 + wave < a.hp;
   const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
   const long sh = (long)s * a.nh + head;

@@ -238,7 +238,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       static bool once2 = (allow_lds(attn_fwd_kernel<T>, 4 * AttnK<T>::TILE), true);
       (void)once2;
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
-      hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3((N + 127) / 128, nh, S), dim3(256), albytes, st, a);
+      hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), albytes, st, a);
       CHECK_LAUNCH();
     }
     {
@@ -422,7 +422,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       (void)once;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3((N + 127) / 128, nh, B), dim3(256), 6 * AttnK<T>::TILE, st, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(((N + 127) / 128) * nh * B), dim3(256), 6 * AttnK<T>::TILE, st, a);
       }
       CHECK_LAUNCH();
       {
@@ -440,7 +440,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       (void)once2;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3((hp + 7) / 8, nh, B), dim3(512), 2 * DkvK<T>::STAGE, st, k);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(((hp + 7) / 8) * nh * B), dim3(512), 2 * DkvK<T>::STAGE, st, k);
       }
       CHECK_LAUNCH();
     }

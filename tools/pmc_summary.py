@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 --pmc CSVs (run on the GPU box): per kernel family the per-launch HBM bytes
+(FETCH_SIZE x2 on gfx950 for wide coalesced reads, WRITE_SIZE), MFMA / LDS busy fractions and effective clock.
+usage: python tools/pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <dir_grbm> <out.json>"""
+import collections, csv, glob, json, re, sys
+
+
+def load(d):
+    fs = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt, dur, seen = collections.Counter(), collections.defaultdict(float), set()
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"\(.*", "", r["Kernel_Name"])
+            if k.startswith("void at::") or "rocclr" in k:
+                k = "torch/other"
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"]); cnt[k] += 1
+                dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    return agg, cnt, dur
+
+
+fa, fc, fd = load(sys.argv[1]); wa, wc, wd = load(sys.argv[2]); sa, sc, sd = load(sys.argv[3]); ga, gc, gd = load(sys.argv[4])
+out = {}
+for k in sd:
+    n = max(sc[k], 1); busy = sa[k]["SQ_BUSY_CYCLES"] or 1; w = sa[k]["SQ_WAVE_CYCLES"] or 1
+    out[k] = {
+        "launches": sc[k], "avg_us": sd[k] / n / 1e3,
+        "hbm_fetch_MB_per_launch": fa[k]["FETCH_SIZE"] * 1024 * 2 / max(fc[k], 1) / 1e6,
+        "hbm_write_MB_per_launch": wa[k]["WRITE_SIZE"] * 1024 / max(wc[k], 1) / 1e6,
+        "mfma_busy_frac": sa[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (busy * 32), "lds_busy_frac": sa[k]["SQ_LDS_IDX_ACTIVE"] / (busy * 8),
+        "lds_conflict_per_active": sa[k]["SQ_LDS_BANK_CONFLICT"] / max(sa[k]["SQ_LDS_IDX_ACTIVE"], 1),
+        "wait_any": sa[k]["SQ_WAIT_ANY"] / w, "wait_inst_any": sa[k]["SQ_WAIT_INST_ANY"] / w, "active_inst_any": sa[k]["SQ_ACTIVE_INST_ANY"] / w,
+        "clock_GHz": ga[k]["GRBM_GUI_ACTIVE"] / 8 / max(gd[k], 1),
+    }
+    o = out[k]
+    o["hbm_GBps"] = (o["hbm_fetch_MB_per_launch"] + o["hbm_write_MB_per_launch"]) * 1e6 / (o["avg_us"] * 1e3) if o["avg_us"] else 0
+json.dump(out, open(sys.argv[5], "w"), indent=1)
+print("wrote", sys.argv[5], len(out), "kernels")
