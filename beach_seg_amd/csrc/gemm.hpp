@@ -50,6 +50,7 @@ struct GemmArgs {
   void* out4;
   int hp, nh;
   float alpha;
+  int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
 
 // ---- shared epilogue: acc[ni][mi][r] = C[mw + mi*16 + (lane&15)][nw + ni*16 + 4*(lane>>4) + r]
@@ -492,6 +493,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
       for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
+  // De-phase the CUs.  All blocks of the first dispatch wave start together and do identical work, so without
+  // this every CU reaches its store burst at the same moment and HBM alternates between idle and saturated
+  // (measured: the stores of a K=1024 tile cost 14 % of the kernel, all of it exposed).  Blocks of the first wave
+  // sleep a different eighth of one tile time; later blocks inherit the phase of the CU they land on.
+  if (blockIdx.x < 256 && gridDim.x > 512) {
+    const int phase = (blockIdx.x >> 3) & 7;
+    const int naps = (phase * nk * g.stagger) >> 7;  // g.stagger = cycles per K tile / 64 (host-tuned)
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) issue(q, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

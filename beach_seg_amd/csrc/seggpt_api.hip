@@ -146,6 +146,8 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
   if (g.a_rpg <= 0) { g.a_rpg = g.M > 0 ? g.M : 1; g.a_gstride = 0; }
+  static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
+  g.stagger = stagger;
   ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
   launch_gemm<T, AM, EPI>(g, st);
 }
@@ -649,6 +651,7 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
   g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.out = out; g.ldo = N;
   hipStream_t st = (hipStream_t)stream;
   static const bool nostore = getenv("BSG_GEMM_NOSTORE") != nullptr;
+  if (getenv("BSG_GEMM_LDO0")) g.ldo = 0;  // diagnostics: every row lands on row 0 (stores stay in L2)
   if (nostore) { gemm<bf16_t, A_PLAIN, EPI_NONE>(&dummy, g, st); CHECK_LAUNCH(); return 0; }
   if (dtype == BSG_DTYPE_F32) { if (bias) gemm<float, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<float, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
   else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
