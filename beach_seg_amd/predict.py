@@ -51,12 +51,31 @@ def _non_overlapping_groups(crops: torch.Tensor) -> list[torch.Tensor]:
 
 @torch.no_grad()
 def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Tensor, crops: torch.Tensor,
-                   out_shape: tuple[int, int], crop_size: int, batch_size: int = 64, date: str = "d0") -> torch.Tensor:
+                   out_shape: tuple[int, int], crop_size: int, batch_size: int = 64, date: str = "d0",
+                   use_graph: bool = False) -> torch.Tensor:
     """Sliding-window inference (BASELINE config 4): images f32 (n,3,S,S) normalised, one prompt per crop_idx.
-    Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`)."""
+    Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`).
+    `use_graph`: replay the network forward from one captured hipGraph (full batches only; the tail runs eagerly)."""
     acc = Accumulator(out_shape, model.conf.classes, model.device)
+    graphed = model.model.capture_forward(batch_size) if use_graph and images.shape[0] >= batch_size else None
     for s in range(0, images.shape[0], batch_size):
         sl = slice(s, s + batch_size)
-        pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
+        n = images[sl].shape[0]
+        if graphed is not None and n == batch_size:
+            pal, pal_norm = model.create_palette(n, train=True)
+            prompt_batch, prompt_masks = model.prepare_prompt(crop_idx[sl], pal, train=False)
+            out = graphed(images[sl].to(model.device), prompt_batch["image"], prompt_masks)
+            pred = model.process_pred_masks(out, pal_norm)
+        else:
+            pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
         acc.update(date, crops[sl], pred.to(torch.uint8), crop_size)
     return acc.result()
+
+
+def grid_crops(height: int, width: int, crop_size: int, stride: int | None = None) -> torch.Tensor:
+    """Regular sliding-window grid (xmin,ymin,xmax,ymax); the last row / column may stick out of the mosaic and is
+    clipped by the vote paste exactly like `Accumulator.update` (`src/predict.py:138-159`)."""
+    stride = stride or crop_size
+    xs = list(range(0, width, stride))
+    ys = list(range(0, height, stride))
+    return torch.tensor([[x, y, x + crop_size, y + crop_size] for y in ys for x in xs], dtype=torch.int32)

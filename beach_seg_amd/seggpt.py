@@ -243,6 +243,12 @@ class SegGptNative(torch.nn.Module):
             N.check(self._lib.bsg_backward(self._h, _stream(), B, _ptr(grad_pred), _ptr(g), _ptr(ws), ws.numel()))
         return g
 
+    def capture_forward(self, batch: int, embedding_type: str = "instance") -> "GraphedForward":
+        """Capture one inference forward (no autograd) of `batch` samples into a hipGraph.  The C ABI enqueues
+        everything on the caller's stream without allocation or synchronisation, so the whole launch sequence
+        (~350 kernels) replays as one graph launch: BASELINE config 4 (sliding-window predict)."""
+        return GraphedForward(self, batch, embedding_type)
+
     def forward(self, pixel_values, prompt_pixel_values, prompt_masks, bool_masked_pos=None, feature_ensemble=None,
                 embedding_type=None, labels=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, **kwargs) -> SegGptImageSegmentationOutput:
@@ -269,3 +275,37 @@ class SegGptNative(torch.nn.Module):
         # `labels` never reach the network under the default mask (HF:706-715); HF's own `loss` output is
         # unused by the reference (src/model.py:292), so it is not computed here.
         return SegGptImageSegmentationOutput(loss=None, pred_masks=pred)
+
+
+class GraphedForward:
+    """hipGraph replay of `SegGptNative` inference at a fixed batch size: copy inputs into the static buffers,
+    replay, read `pred` (f32 (B,3,H,W), overwritten by the next call)."""
+
+    def __init__(self, model: SegGptNative, batch: int, embedding_type: str = "instance"):
+        if embedding_type not in ("instance", "semantic"):
+            raise ValueError(f"Embedding type should be either 'semantic' or 'instance', but got {embedding_type}")
+        self.model, self.batch = model, batch
+        emb = 0 if embedding_type == "instance" else 1
+        dev = model.device
+        Hh, W = model.geometry.image_size[0] // 2, model.geometry.image_size[1]
+        self.pix = torch.zeros(batch, 3, Hh, W, device=dev)
+        self.prm = torch.zeros_like(self.pix)
+        self.pmask = torch.zeros_like(self.pix)
+        model.workspace(batch, False)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up outside capture: one-time kernel attribute calls happen here
+            for _ in range(2):
+                model._run_forward(self.pix, self.prm, self.pmask, emb, train=False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.pred = model._run_forward(self.pix, self.prm, self.pmask, emb, train=False)
+
+    @torch.no_grad()
+    def __call__(self, pixel_values, prompt_pixel_values, prompt_masks) -> torch.Tensor:
+        self.pix.copy_(pixel_values)
+        self.prm.copy_(prompt_pixel_values)
+        self.pmask.copy_(prompt_masks)
+        self.graph.replay()
+        return self.pred

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 (a parity-test configuration, NOT the headline bench line): inference-only sliding window
+over a synthetic mosaic, 1 GPU, network forward replayed from a captured hipGraph, votes accumulated on device.
+
+    python bench_predict.py [--size 8192] [--batch 64] [--crop 112]
+
+The reference's loop (`src/predict.py:232-262`) runs batch_size 1 on the CPU; here the 5,476 windows of an
+8192 x 8192 mosaic are resized to 448 x 448 on device (bilinear here -- PIL-exact bicubic is a section 8 f-3 "next"
+row), pushed through the ViT-L forward in batches, decoded, nearest-resized and voted without leaving the GPU."""
+import argparse, json, sys, time
+from pathlib import Path
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from beach_seg_amd import ml_util
+from beach_seg_amd.config import BeachSegConfig
+from beach_seg_amd.model import PromptModel
+from beach_seg_amd.predict import Accumulator, grid_crops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--crop", type=int, default=112)
+    ap.add_argument("--prompts", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    conf = BeachSegConfig(checkpoint="synthetic:vit_large", precision="bf16-true", crop_size=a.crop, batch_size=a.batch)
+    pm = PromptModel(conf, device=dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    S = conf.inpt_size
+    pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, S, S, device=dev, generator=g),
+                                 "mask": torch.randint(0, 4, (S, S), device=dev, generator=g, dtype=torch.uint8),
+                                 "nodata": torch.zeros(S, S, dtype=torch.bool)} for i in range(a.prompts)])
+    mosaic = (torch.rand(a.size // 64, a.size // 64, 3, device=dev, generator=g).repeat_interleave(64, 0).repeat_interleave(64, 1) * 255).to(torch.uint8)
+    crops = grid_crops(a.size, a.size, a.crop)
+    n = crops.shape[0]
+    graphed = None if a.no_graph else pm.model.capture_forward(a.batch)
+    acc = Accumulator((a.size, a.size), conf.classes, dev)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); t_net = 0.0
+    for s in range(0, n, a.batch):
+        cb = crops[s:s + a.batch]
+        tiles = []
+        for x0, y0, x1, y1 in cb.tolist():  # clipped windows are zero-padded like padded_crop
+            t = torch.zeros(a.crop, a.crop, 3, dtype=torch.uint8, device=dev)
+            ys, xs = min(y1, a.size) - y0, min(x1, a.size) - x0
+            t[:ys, :xs] = mosaic[y0:y0 + ys, x0:x0 + xs]
+            tiles.append(t)
+        img = torch.stack(tiles).permute(0, 3, 1, 2).float() / 255.0
+        img = ml_util.normalize(F.interpolate(img, size=(S, S), mode="bilinear", align_corners=False))
+        idx = torch.arange(s, s + img.shape[0]) % a.prompts
+        pal, pal_norm = pm.create_palette(img.shape[0], train=True)
+        pb, pmasks = pm.prepare_prompt(idx, pal, train=False)
+        if graphed is not None and img.shape[0] == a.batch:
+            out = graphed(img, pb["image"], pmasks)
+        else:
+            out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
+        pred = pm.process_pred_masks(out, pal_norm)
+        acc.update("d0", cb, pred.to(torch.uint8), a.crop)
+    result = acc.result()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(json.dumps({"config": f"predict sliding window {a.size}x{a.size}, crop {a.crop}, batch {a.batch}, hipGraph={not a.no_graph}",
+                      "tiles": n, "seconds": round(dt, 3), "tiles_per_s": round(n / dt, 1), "fwd_ms_per_tile": round(dt / n * 1e3, 3),
+                      "inference_tflops": round(n / dt * 1.5897, 1), "classes_present": torch.unique(result).tolist()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -94,3 +94,18 @@ def test_validation_forward_and_predict_mosaic():
     batch = {"image": images[:2], "mask": torch.randint(1, 4, (2, 1, 64, 64), dtype=torch.uint8), "crop_idx": torch.tensor([2, 3])}
     l = pm.validation_step(batch)
     assert torch.isfinite(l) and int(pm.val_metrics.state().sum()) > 0
+
+
+def test_hipgraph_replay_equals_eager_forward():
+    """BASELINE config 4: the forward is capturable (no allocation / synchronisation inside the C ABI) and a graph
+    replay reproduces the eager launch sequence bit for bit."""
+    geo = SegGptGeometry.small()
+    net = SegGptNative(synth_state_dict(geo, seed=2), geo, device=DEV, dtype=torch.bfloat16)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda: torch.randn(2, 3, 448, 448, device=DEV, generator=g)
+    graphed = net.capture_forward(2)
+    for _ in range(2):
+        pix, prm, pm = mk(), mk(), mk()
+        with torch.no_grad():
+            eager = net(pixel_values=pix, prompt_pixel_values=prm, prompt_masks=pm).pred_masks.clone()
+        assert torch.equal(graphed(pix, prm, pm), eager)
