@@ -287,3 +287,28 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ d
     if (lane == 0) delta[((long)s * nh + h) * (hp * 32) + qpad] = t;
   }
 }
+
+
+// feature_ensemble (HF:414-423): on the bottom (query) half of the canvas replace the attention-block output a[s]
+// by its mean over the streams of a group.  The proj GEMM has already written x_mid = x_in + a, so a is recovered
+// as x_mid - x_in (fp32 residual stream).  groups = 2 (per stream kind, blocks before the merge) or 1.
+__global__ void ensemble_fixup_kernel(const float* __restrict__ x_in, float* __restrict__ x_mid, int S, int groups, int N,
+                                      int D) {
+  const int per = S / groups, half = N / 2;
+  const long n4 = (long)groups * half * D / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int grp = e / ((long)half * D);
+    const long r = e % ((long)half * D);  // offset inside the bottom half of one stream
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < per; ++m) {
+      const long o = ((long)(grp * per + m) * N + half) * D + r;
+      acc += *(const f32x4*)(x_mid + o) - *(const f32x4*)(x_in + o);
+    }
+    acc *= 1.0f / per;
+    for (int m = 0; m < per; ++m) {
+      const long o = ((long)(grp * per + m) * N + half) * D + r;
+      *(f32x4*)(x_mid + o) = *(const f32x4*)(x_in + o) + acc;
+    }
+  }
+}

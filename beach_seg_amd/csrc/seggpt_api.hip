@@ -176,7 +176,7 @@ static void ln_bwd(const Ctx<T>& c, const T* dy, long lddy, const float* x, cons
 }
 
 template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int B, const float* pix, const float* prm,
-                                              const float* pmask, int emb, float* pred, void* ws, int train) {
+                                              const float* pmask, int emb, float* pred, void* ws, int train, int fe = 0) {
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, train), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
   const int hp = m->hp, wp = m->wp, nt = m->c.num_taps;
@@ -249,6 +249,15 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       g.bias = (const float*)m->lw(l, 7); g.out = x_mid; g.ldo = D; g.aux = x_cur; g.ldaux = D;
       gemm<T, A_PLAIN, EPI_BIAS_RESID>(m, g, st);
       CHECK_LAUNCH();
+    }
+    if (fe) {  // HF:414-423
+      const int cond = m->c.merge_index > l ? 2 : 1;
+      if (S / 2 >= cond) {
+        const long n4 = (long)cond * (N / 2) * D / 4;
+        hipLaunchKernelGGL(ensemble_fixup_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 65535)), dim3(256), 0, st,
+                           (const float*)x_cur, x_mid, S, cond, N, D);
+        CHECK_LAUNCH();
+      }
     }
     ln_fwd<T>(c, x_mid, m->lw(l, 8), m->lw(l, 9), ln_out, D, rows);
     CHECK_LAUNCH();
@@ -564,6 +573,20 @@ int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values
   return m->c.dtype == BSG_DTYPE_F32
              ? forward_impl<float>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward)
              : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward);
+}
+
+int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
+                         const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace,
+                         size_t workspace_bytes) {
+  if (!m || !pixel_values || !prompt_pixel_values || !prompt_masks || !pred_masks || !workspace) return fail("bsg_forward_ensemble: null argument");
+  if (batch <= 0) return fail("batch must be positive");
+  if (embedding_type != 0 && embedding_type != 1)
+    return fail("Embedding type should be either 'semantic' or 'instance', but got %d", embedding_type);
+  if (workspace_bytes < bsg_workspace_bytes(m, batch, 0)) return fail("workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  return m->c.dtype == BSG_DTYPE_F32
+             ? forward_impl<float>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1)
+             : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1);
 }
 
 int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values, void* workspace,

@@ -221,15 +221,19 @@ class SegGptNative(torch.nn.Module):
             out[name] = (ms.value, fl.value, n.value)
         return out
 
-    def _run_forward(self, pix, prm, pmask, emb: int, train: bool) -> torch.Tensor:
+    def _run_forward(self, pix, prm, pmask, emb: int, train: bool, ensemble: bool = False) -> torch.Tensor:
         B = pix.shape[0]
         H, W = self.geometry.image_size
         pix, prm, pmask = (t.to(self._device, torch.float32).contiguous() for t in (pix, prm, pmask))
         pred = torch.empty((B, 3, H, W), dtype=torch.float32, device=self._device)
         ws = self.workspace(B, train)
         with torch.cuda.device(self._device):
-            N.check(self._lib.bsg_forward(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb, _ptr(pred),
-                                          _ptr(ws), ws.numel(), int(train)))
+            if ensemble:
+                N.check(self._lib.bsg_forward_ensemble(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb,
+                                                       _ptr(pred), _ptr(ws), ws.numel()))
+            else:
+                N.check(self._lib.bsg_forward(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb, _ptr(pred),
+                                              _ptr(ws), ws.numel(), int(train)))
         self._last_ws = ws if train else None
         return pred
 
@@ -253,9 +257,8 @@ class SegGptNative(torch.nn.Module):
                 embedding_type=None, labels=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, **kwargs) -> SegGptImageSegmentationOutput:
         g = self.geometry
-        if bool_masked_pos is not None or feature_ensemble:
-            raise NotImplementedError("only the reference's call pattern is built: default bool_masked_pos, "
-                                      "feature_ensemble=False (src/model.py:139-144, 245-251, 282-288)")
+        if bool_masked_pos is not None:
+            raise NotImplementedError("only the default bool_masked_pos (bottom half masked, HF:902-909) is built")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / hidden states are never materialised by the fused kernels")
         if pixel_values.shape[1] != g.num_channels:  # HF:112-115
@@ -271,6 +274,11 @@ class SegGptNative(torch.nn.Module):
             raise ValueError(f"Embedding type should be either 'semantic' or 'instance', but got {embedding_type}")
         emb = 0 if embedding_type == "instance" else 1
         need_grad = torch.is_grad_enabled() and prompt_pixel_values.requires_grad
+        if feature_ensemble:  # few-shot inference of src/predict_no_prompt.py:283-304 (HF:414-423)
+            if need_grad:
+                raise NotImplementedError("feature_ensemble is an inference path: no backward is built for it")
+            return SegGptImageSegmentationOutput(loss=None, pred_masks=self._run_forward(
+                pixel_values.detach(), prompt_pixel_values.detach(), prompt_masks.detach(), emb, train=False, ensemble=True))
         pred = _SegGptFn.apply(self, pixel_values, prompt_pixel_values, prompt_masks, emb, need_grad)
         # `labels` never reach the network under the default mask (HF:706-715); HF's own `loss` output is
         # unused by the reference (src/model.py:292), so it is not computed here.

@@ -73,6 +73,14 @@ int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values
                 const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace,
                 size_t workspace_bytes, int save_for_backward);
 
+/* The same forward with feature_ensemble=True (HF:414-423; the few-shot caller src/predict_no_prompt.py:283-304): the
+ * `batch` rows are K prompts for ONE query; in every block the query-half of the attention-block output is replaced
+ * by its mean over the prompts (per stream kind before the merge block, over all rows from the merge block on).
+ * Inference only: no activations are saved. */
+int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pixel_values,
+                         const float* prompt_pixel_values, const float* prompt_masks, int embedding_type,
+                         float* pred_masks, void* workspace, size_t workspace_bytes);
+
 /* dgrad-only backward of the frozen network (what Lightning's loss.backward() executes, src/model.py:233-269):
  * grad_pred f32 (B,3,H,W) -> grad_prompt_pixel_values f32 (B,3,H/2,W).  Weights receive no gradient
  * (src/util/ml_util.py:9-10). */

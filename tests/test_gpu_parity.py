@@ -271,3 +271,16 @@ def test_full_geometry_batch_invariance_and_linearity():
     (g2,) = torch.autograd.grad(out, p, 2 * gp)
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     assert torch.equal(g2, 2 * g1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
+    """`feature_ensemble=True` with K=3 prompts for one query (HF:414-423), against the
+    vector HF itself produced."""
+    rec = np.load(golden_dir / "tiny_feature_ensemble.npz")
+    model = model_for("tiny", int(rec["wseed"]), dtype)
+    with torch.no_grad():
+        out = model(pixel_values=torch.from_numpy(rec["pixel_values"]).to(DEV),
+                    prompt_pixel_values=torch.from_numpy(rec["prompt_pixel_values"]).to(DEV),
+                    prompt_masks=torch.from_numpy(rec["prompt_masks"]).to(DEV), feature_ensemble=True)
+    assert relmax(out.pred_masks, rec["pred"]) < TOL[dtype]["t"]
