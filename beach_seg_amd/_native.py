@@ -19,7 +19,7 @@ SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble", "bsg_backward_rows",
 )
 
 
@@ -60,6 +60,7 @@ def load():
     lib.bsg_workspace_region.argtypes = [vp, i, i, C.c_char_p, i, C.POINTER(sz), C.POINTER(sz)]
     lib.bsg_forward.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, sz, i]
     lib.bsg_backward.argtypes = [vp, vp, i, vp, vp, vp, sz]
+    lib.bsg_backward_rows.argtypes = [vp, vp, i, vp, i, vp, vp, sz]
     lib.bsg_forward_ensemble.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, sz]
     lib.bsg_loss_scratch_bytes.argtypes = [i, i]
     lib.bsg_loss_scratch_bytes.restype = sz

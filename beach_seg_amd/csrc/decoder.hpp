@@ -18,6 +18,7 @@ struct ConvArgs {
   float* pred;                           // fp32 NCHW [B][3][H][W]
   int H, W;
   float eps;
+  int ty0;  // first 8-row output tile (dgrad over a row window)
 };
 
 // Workgroup = 8 x 32 output pixels; wave w owns rows 2w, 2w+1 (64 pixels) x 64 output channels (4x4 MFMA 16x16).
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char halo[];  // [10][34] pixels x PB, chunk-swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8, b = blockIdx.z;
+  const int x0 = blockIdx.x * 32, y0 = (blockIdx.y + a.ty0) * 8, b = blockIdx.z;
   const char* img = (const char*)a.in + (long)b * a.H * a.W * PB;
 
   for (int i = tid; i < 340 * CPP; i += 256) {
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
@@ -136,14 +138,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ conv_out,
                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                         const float* __restrict__ head_w, T* __restrict__ dconv, int B,
-                                                        int H, int W, float eps) {
-  const long hw = (long)H * W, total = (long)B * hw;
+                                                        int H, int W, float eps, int row0) {
+  const long hw = (long)H * W, win = (long)(H - row0) * W, total = (long)B * win;  // rows [row0, H) of every image
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const long p = gid >> 2;
+  const long pl = gid >> 2;
   const int c0 = (int)(gid & 3) * 16;
-  if (p >= total) return;  // total*4 is a multiple of 64: whole waves exit together
-  const int b = p / hw;
-  const long yx = p % hw;
+  if (pl >= total) return;  // total*4 is a multiple of 64: whole waves exit together
+  const int b = pl / win;
+  const long yx = (long)row0 * W + pl % win;
+  const long p = (long)b * hw + yx;
   const float d0 = dpred[(long)b * 3 * hw + yx], d1 = dpred[(long)b * 3 * hw + hw + yx],
               d2 = dpred[(long)b * 3 * hw + 2 * hw + yx];
   typedef typename Traits<T>::Vec4 V4;

@@ -50,6 +50,11 @@ struct GemmArgs {
   void* out4;
   int hp, nh;
   float alpha;
+  // A_FEAT / EPI_PLAIN row windows: GEMM row m <-> image m / a_rpg, token t_off + m % a_rpg (A_FEAT), and output
+  // row (m / o_rpg) * o_gstride + o_off + m % o_rpg (EPI_PLAIN); o_rpg == 0 means the identity
+  int t_off;
+  int o_rpg;
+  long o_gstride, o_off;
   int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
 
@@ -103,7 +108,8 @@ DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw,
         const int p1 = col >> 10, p2 = (col >> 6) & 15, c = col & 63;
         off = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
       } else {
-        off = (long)m * g.ldo + col;
+        const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
+        off = orow * g.ldo + col;
       }
       if (ok) *(u32x4*)((bf16_t*)g.out + off) = out;
       if (EPI == EPI_BIAS_GELU) {
@@ -139,7 +145,8 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         v += b;
       }
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
-        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+        const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
+        *(typename Traits<T>::Vec4*)((T*)g.out + orow * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       } else if (EPI == EPI_BIAS_GELU) {
         if (g.out2)
           *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     if (AMODE == A_PLAIN) {
       base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
     } else {  // NHWC feature map (B, himg, wimg, 64): row m = (b, ph, pw) starts at pixel (ph*16, pw*16)
-      const int b = m / g.tokens, t = m % g.tokens;
+      const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
       const int ph = t / g.wp, pw = t % g.wp;
       base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
     }
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
     if (AMODE == A_PLAIN) {
       base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
     } else {
-      const int b = m / g.tokens, t = m % g.tokens;
+      const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
       const int ph = t / g.wp, pw = t % g.wp;
       base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
     }
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
         if (AMODE == A_PLAIN) {
           base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
         } else {
-          const int b = m / g.tokens, t = m % g.tokens;
+          const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
           const int ph = t / g.wp, pw = t % g.wp;
           base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
         }

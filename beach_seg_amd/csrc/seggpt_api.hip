@@ -145,7 +145,7 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
-  if (g.a_rpg <= 0) { g.a_rpg = g.M > 0 ? g.M : 1; g.a_gstride = 0; }
+  if (g.a_rpg <= 0) { g.a_rpg = AM == A_FEAT ? g.tokens : (g.M > 0 ? g.M : 1); g.a_gstride = 0; }
   static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
   g.stagger = stagger;
   ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
@@ -320,7 +320,8 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   return 0;
 }
 
-template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int B, const float* dpred, float* gprompt, void* ws) {
+template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int B, const float* dpred, float* gprompt, void* ws,
+                                               int first_row = 0) {
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, 1), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
   const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, H = m->c.canvas_h, W = m->c.canvas_w;
@@ -349,23 +350,32 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   float* relwT = c.template at<float>("relwT");
 
   {
-    const long total = (long)B * H * W;
+    // grad_pred is zero on canvas rows < first_row (the reference loss only covers the bottom half, src/model.py:53-57):
+    // the 3x3 dgrad reaches one row above, so only token rows >= ph0 can carry a gradient into the encoder.
+    const int ph0 = first_row > 0 ? (first_row - 1) / 16 : 0;
+    const int hb0 = std::max(0, 16 * ph0 - 8), ty0 = 2 * ph0, ntok = (hp - ph0) * wp;
+    const long total = (long)B * (H - hb0) * W;
     hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
                        c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
-                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps);
+                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0);
     CHECK_LAUNCH();
     ConvArgs a{};
-    a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
+    a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps; a.ty0 = ty0;
     const int lds = 340 * 64 * sizeof(T);
     static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, 340 * 64 * sizeof(T)), true);
     (void)once;
     {
-      ProfScope ps(m, st, PC_CONV, 2.0 * B * H * W * 9 * 64 * 64);
-      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8, B), dim3(256), lds, st, a);
+      ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * 8) * W * 9 * 64 * 64);
+      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8 - ty0, B), dim3(256), lds, st, a);
     }
     CHECK_LAUNCH();
+    if (ph0 > 0) {  // token rows < ph0 receive exactly zero
+      if (hipMemset2DAsync(dtaps, (size_t)N * nt * D * sizeof(T), 0, (size_t)ph0 * wp * nt * D * sizeof(T), B, st) != hipSuccess)
+        return fail("memset2d failed");
+    }
     GemmArgs g{};
-    g.A = dfeat; g.W = m->gw(7); g.M = rows; g.N = nt * D; g.K = 256 * 64; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
+    g.A = dfeat; g.W = m->gw(7); g.M = B * ntok; g.N = nt * D; g.K = 256 * 64; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
+    g.a_rpg = ntok; g.t_off = ph0 * wp; g.o_rpg = ntok; g.o_gstride = N; g.o_off = ph0 * wp;
     g.out = dtaps; g.ldo = (long)nt * D;
     gemm<T, A_FEAT, EPI_PLAIN>(m, g, st);
     CHECK_LAUNCH();
@@ -589,13 +599,20 @@ int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pix
              : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1);
 }
 
-int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values, void* workspace,
-                 size_t workspace_bytes) {
+int bsg_backward_rows(bsg_model* m, void* stream, int batch, const float* grad_pred, int first_row,
+                      float* grad_prompt_pixel_values, void* workspace, size_t workspace_bytes) {
   if (!m || !grad_pred || !grad_prompt_pixel_values || !workspace) return fail("bsg_backward: null argument");
   if (workspace_bytes < bsg_workspace_bytes(m, batch, 1)) return fail("workspace too small for backward");
+  if (first_row < 0 || first_row >= m->c.canvas_h) return fail("first_row %d outside the canvas", first_row);
   hipStream_t st = (hipStream_t)stream;
-  return m->c.dtype == BSG_DTYPE_F32 ? backward_impl<float>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace)
-                                     : backward_impl<bf16_t>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace);
+  return m->c.dtype == BSG_DTYPE_F32
+             ? backward_impl<float>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace, first_row)
+             : backward_impl<bf16_t>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace, first_row);
+}
+
+int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values, void* workspace,
+                 size_t workspace_bytes) {
+  return bsg_backward_rows(m, stream, batch, grad_pred, 0, grad_prompt_pixel_values, workspace, workspace_bytes);
 }
 
 static const int kLossBlocks = 1024;

@@ -69,7 +69,7 @@ class PromptTrainEngine:
         prompts = ops.prompt_gather(self.params, prompt_idx)  # stack + Normalize
         pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True)
         loss, gpred = ops.loss_fwd_bwd(pred, label_color, yesdata, self.loss_beta, self.loss_variant, True)
-        gpix = m._run_backward(gpred, B)
+        gpix = m._run_backward(gpred, B, first_row=pred.shape[2] // 2)  # the loss gradient is zero on the prompt half
         ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
         self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
         reduce_prompt_grads(self._flat, self.pg)  # RCCL over xGMI when world > 1

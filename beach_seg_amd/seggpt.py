@@ -237,14 +237,16 @@ class SegGptNative(torch.nn.Module):
         self._last_ws = ws if train else None
         return pred
 
-    def _run_backward(self, grad_pred: torch.Tensor, B: int) -> torch.Tensor:
+    def _run_backward(self, grad_pred: torch.Tensor, B: int, first_row: int = 0) -> torch.Tensor:
+        """`first_row` > 0: the caller guarantees grad_pred == 0 on canvas rows < first_row (bsg_backward_rows)."""
         if self._last_ws is None:
             raise RuntimeError("backward without a forward that saved activations")
         H, W = self.geometry.image_size
         g = torch.empty((B, 3, H // 2, W), dtype=torch.float32, device=self._device)
         ws = self._last_ws
         with torch.cuda.device(self._device):
-            N.check(self._lib.bsg_backward(self._h, _stream(), B, _ptr(grad_pred), _ptr(g), _ptr(ws), ws.numel()))
+            N.check(self._lib.bsg_backward_rows(self._h, _stream(), B, _ptr(grad_pred), int(first_row), _ptr(g), _ptr(ws),
+                                                ws.numel()))
         return g
 
     def capture_forward(self, batch: int, embedding_type: str = "instance") -> "GraphedForward":

@@ -87,6 +87,12 @@ int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pix
 int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values,
                  void* workspace, size_t workspace_bytes);
 
+/* Same, for a grad_pred the caller guarantees to be zero on canvas rows < first_row (what bsg_loss_fwd_bwd produces
+ * with first_row = H/2: the reference loss only covers the query half, src/model.py:53-57).  The decoder dgrad then
+ * runs only over the token rows that can receive a gradient.  first_row = 0 is bsg_backward. */
+int bsg_backward_rows(bsg_model* m, void* stream, int batch, const float* grad_pred, int first_row,
+                      float* grad_prompt_pixel_values, void* workspace, size_t workspace_bytes);
+
 /* SegGptLoss of the reference (src/model.py:40-64).  variant 0 reproduces the unsqueeze(1) batch broadcast
  * of :61; variant 1 is the per-sample masked mean (identical at B = 1).  pred f32 (B,3,2h,w), labels f32
  * (B,3,h,w), yesdata u8 (B,h,w).  loss_out: 1 float (device).  grad_pred may be NULL.
