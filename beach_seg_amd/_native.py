@@ -8,7 +8,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "libbsg_hip.so"
+_LIB_PATH = Path(os.environ.get("BSG_LIB", Path(__file__).resolve().parent / "libbsg_hip.so"))  # BSG_LIB: experiments
 _lib = None
 
 BSG_DTYPE_F32, BSG_DTYPE_BF16 = 0, 1

@@ -236,11 +236,15 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o; a.ldo = D;
       a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      const int albytes = 4 * AttnK<T>::TILE;
-      static bool once2 = (allow_lds(attn_fwd_kernel<T>, 4 * AttnK<T>::TILE), true);
+      static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
+      static const bool piped = getenv("BSG_ATTN_FWD_PIPE") != nullptr;  // software-pipelined variant: measured 3 % slower (2 waves/SIMD)
+      static bool once2 = (allow_lds(attn_fwd_kernel<T>, 160 * 1024), allow_lds(attn_fwd_pipe_kernel<T>, 160 * 1024), true);
       (void)once2;
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
-      hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), albytes, st, a);
+      if (piped)
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), 5 * AttnK<T>::TILE + ldspad, st, a);
+      else
+        hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
       CHECK_LAUNCH();
     }
     {
