@@ -101,6 +101,14 @@ DEVI float gelu_f(float x) {
   const float er = copysignf(erf_half_exp(ax, e), x);
   return 0.5f * x * (1.0f + er);
 }
+// gelu(x) and gelu'(x) from one exp and one erf evaluation (forward epilogue that also saves the derivative)
+DEVI void gelu_both_f(float x, float& y, float& dy) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  const float cdf = 0.5f * (1.0f + copysignf(erf_half_exp(ax, e), x));
+  y = x * cdf;
+  dy = fmaf(0.39894228040143267794f * x, e, cdf);
+}
 DEVI float gelu_grad_f(float x) {
   const float ax = fabsf(x);
   const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);

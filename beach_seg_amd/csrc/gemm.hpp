@@ -13,12 +13,12 @@
 enum AMode { A_PLAIN = 0, A_FEAT = 1 };
 enum EpiMode {
   EPI_BIAS = 0,       // out[m][n] = T(acc + bias[n])
-  EPI_BIAS_GELU = 1,  // out2[m][n] = T(h = acc + bias[n]) (if out2), out[m][n] = T(gelu(h))
+  EPI_BIAS_GELU = 1,  // h = acc + bias[n]: out[m][n] = T(gelu(h)), out2[m][n] = T(gelu'(h)) (if out2: saved for dgrad)
   EPI_BIAS_RESID = 2, // outf[m][n] = resid[m][n] + acc + bias[n]            (fp32 residual stream)
   EPI_EMBED = 3,      // outf[m][n] = acc + table[kind(m)][tok(m)][n]        (patch embed + tokens)
   EPI_FEAT = 4,       // decoder_embed: pixel-shuffle store into NHWC feature map (+bias)
   EPI_PLAIN = 5,      // out[m][n] = T(acc)
-  EPI_GELU_BWD = 6,   // out[m][n] = T(acc * gelu'(aux[m][n]))
+  EPI_GELU_BWD = 6,   // out[m][n] = T(acc * aux[m][n]),  aux = gelu'(h) saved by EPI_BIAS_GELU
   EPI_UNPATCH = 7,    // patch-embed dgrad: scatter rows into the (B,3,H/2,W) fp32 prompt-pixel gradient
   EPI_NONE = 9,       // diagnostics: no stores (accumulators kept alive), to price the epilogue
   EPI_RELPOS = 8,     // per head (blockIdx.y): q . [rel_pos_h; rel_pos_w]^T scattered into the relh / relw tables
@@ -82,13 +82,15 @@ DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw,
       f32x4 v = acc[ni][mi];
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT) v += *(const f32x4*)(g.bias + n);
       if (EPI == EPI_BIAS_GELU) {
-        lo2[ni] = pack_bf16x2(v[0], v[1]);
-        hi2[ni] = pack_bf16x2(v[2], v[3]);
-        v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+        f32x4 y, dy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float yy, dd; gelu_both_f(v[r], yy, dd); y[r] = yy; dy[r] = dd; }
+        lo2[ni] = pack_bf16x2(dy[0], dy[1]);
+        hi2[ni] = pack_bf16x2(dy[2], dy[3]);
+        v = y;
       } else if (EPI == EPI_GELU_BWD) {
         const bf16x4 hp = *(const bf16x4*)((const bf16_t*)g.aux + (long)mc * g.ldaux + n);
-        v = f32x4{v[0] * gelu_grad_f((float)hp[0]), v[1] * gelu_grad_f((float)hp[1]), v[2] * gelu_grad_f((float)hp[2]),
-                  v[3] * gelu_grad_f((float)hp[3])};
+        v = f32x4{v[0] * (float)hp[0], v[1] * (float)hp[1], v[2] * (float)hp[2], v[3] * (float)hp[3]};
       }
       lo[ni] = pack_bf16x2(v[0], v[1]);
       hi[ni] = pack_bf16x2(v[2], v[3]);
@@ -148,10 +150,12 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
         *(typename Traits<T>::Vec4*)((T*)g.out + orow * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       } else if (EPI == EPI_BIAS_GELU) {
+        f32x4 y, dy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { float yy, dd; gelu_both_f(v[r], yy, dd); y[r] = yy; dy[r] = dd; }
         if (g.out2)
-          *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
-            pack4<T>(gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3]));
+          *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(dy[0], dy[1], dy[2], dy[3]);
+        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(y[0], y[1], y[2], y[3]);
       } else if (EPI == EPI_BIAS_RESID) {
         const f32x4 r = *(const f32x4*)((const float*)g.aux + (long)m * g.ldaux + n);
         *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
@@ -170,8 +174,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       } else if (EPI == EPI_GELU_BWD) {
         const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
         *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
-            pack4<T>(v[0] * gelu_grad_f(to_f32(h[0])), v[1] * gelu_grad_f(to_f32(h[1])),
-                     v[2] * gelu_grad_f(to_f32(h[2])), v[3] * gelu_grad_f(to_f32(h[3])));
+            pack4<T>(v[0] * to_f32(h[0]), v[1] * to_f32(h[1]), v[2] * to_f32(h[2]), v[3] * to_f32(h[3]));
       } else if (EPI == EPI_RELPOS) {
         // column n of [rel_pos_h (2hp-1 rows); rel_pos_w (2wp-1 rows)]: rel index r <-> key kh = qh + hp-1 - r
         // (HF:236-266 at q_size == k_size); only the entries that land inside the key grid are stored.
