@@ -145,10 +145,36 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
+  const bool plain_rows = AM == A_PLAIN && g.a_rpg <= 0;
   if (g.a_rpg <= 0) { g.a_rpg = AM == A_FEAT ? g.tokens : (g.M > 0 ? g.M : 1); g.a_gstride = 0; }
   static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
   g.stagger = stagger;
   ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
+  // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
+  // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
+  // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
+  static const bool split_tail = !getenv("BSG_GEMM_NO_TAIL_SPLIT");
+  constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
+  if (split_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
+    const long tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
+    const long full = tiles / 256, rem = tiles % 256;
+    const long tm_main = (full * 256) / tn;  // row tiles that fit in the full rounds
+    if (full >= 3 && rem > 0 && rem < 77 && tm_main > 0 && tm_main < tm) {
+      GemmArgs a = g, b = g;
+      a.M = (int)(tm_main * 256);
+      b.M = g.M - a.M;
+      b.A = (const char*)g.A + (long)a.M * g.lda * sizeof(T);
+      const size_t oes = EPI == EPI_BIAS_RESID ? 4 : sizeof(T);
+      b.out = (char*)g.out + (long)a.M * g.ldo * oes;
+      if (g.out2) b.out2 = (char*)g.out2 + (long)a.M * g.ldo * oes;
+      if (g.aux) b.aux = (const char*)g.aux + (long)a.M * g.ldaux * (EPI == EPI_BIAS_RESID ? 4 : sizeof(T));
+      a.a_rpg = a.M; b.a_rpg = b.M;
+      launch_gemm<T, AM, EPI>(a, st);
+      const int tiles_b = ((b.M + 127) / 128) * ((b.N + 127) / 128);
+      hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EPI>), dim3(tiles_b, 1), dim3(256), 65536, st, b);
+      return;
+    }
+  }
   launch_gemm<T, AM, EPI>(g, st);
 }
 
