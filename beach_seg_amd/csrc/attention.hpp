@@ -28,7 +28,7 @@ struct AttnArgs {
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
   float* lse2;        // [S][nh][Hp*32] (row-padded)  log2-domain logsumexp of the logits
-  const float* delta; // backward: [S][nh][Hp*32]  rowsum(dO * O)
+  float* delta;       // backward: [S][nh][Hp*32]  rowsum(dO * O): WRITTEN by the dQ kernel (from `out` = O), read by dK/dV
   void* dq;  // backward outputs, T [S*N][ld] at the q/k/v column offsets of the dqkv buffer
   void* dk;
   void* dv;
@@ -412,7 +412,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   float* drelh_q = a.drelh + (sh * a.N + q) * a.hp;
   const float c2 = a.scale * 1.44269504088896340736f;
   const float lse = a.lse2[sh * npad + qpad];
-  const float dl = a.delta[sh * npad + qpad];
+  // delta[q] = sum_d dO[q][d] O[q][d]: each half-wave lane holds half of the row; published for the dK/dV kernel
+  float dl = 0.f;
+  {
+    const char* orow = (const char*)a.out + (((long)s * a.N + q) * a.ldo + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) {
+      const Chunk oc = *(const Chunk*)(orow + (2 * ks + h) * 16);
+#pragma unroll
+      for (int j = 0; j < Traits<T>::EPC; ++j) dl += to_f32(dof[ks][j]) * to_f32(oc[j]);
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    if (h == 0 && q0 + col < a.N) a.delta[sh * npad + qpad] = dl;
+  }
   f32x16 dqt[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }

@@ -449,9 +449,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       CHECK_LAUNCH();
     }
     {  // attention backward on the B image streams
-      hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, st, (const T*)dn_b, attn_o, (long)D, delta,
-                         B, N, hp, wp, nh);
-      CHECK_LAUNCH();
       {
         RelTabArgs r{};
         r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relh = relh; r.relw = relw; r.relhT = relhT; r.relwT = relwT;
@@ -467,7 +464,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       CHECK_LAUNCH();
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.relh = relh;
-      a.relw = relw; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.dq = dqkv; a.drelh = drelh; a.drelw = drelw;
+      a.relw = relw; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv; a.drelh = drelh; a.drelw = drelw;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static bool once = (allow_lds(attn_bwd_dq_kernel<T>, 6 * AttnK<T>::TILE), true);
       (void)once;
