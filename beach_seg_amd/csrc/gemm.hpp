@@ -55,6 +55,7 @@ struct GemmArgs {
   int t_off;
   int o_rpg;
   long o_gstride, o_off;
+  int group_m;  // v3: row tiles per L2 group (0 = 4)
   int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
 
@@ -441,9 +442,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   const int nwg = tiles_m * tiles_n;
   int bid = xcd_remap(blockIdx.x, nwg);
   // groups of 4 row tiles: the blocks resident on one XCD at a time share 4 activation panels and a few weight panels
-  const int gsz = 4 * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
-  const int gm = min(4, tiles_m - grp * 4);
-  const int tm = grp * 4 + rem % gm, tn = rem / gm;
+  const int GM = g.group_m > 0 ? g.group_m : 4;
+  const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
+  const int gm = min(GM, tiles_m - grp * GM);
+  const int tm = grp * GM + rem % gm, tn = rem / gm;
   const int m0 = tm << 8, n0 = tn << 8;
   const int head = blockIdx.y;
   const int wm = wave >> 2, wn = wave & 3;

@@ -149,6 +149,8 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   if (g.a_rpg <= 0) { g.a_rpg = AM == A_FEAT ? g.tokens : (g.M > 0 ? g.M : 1); g.a_gstride = 0; }
   static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
   g.stagger = stagger;
+  static const int group_m = getenv("BSG_GEMM_GROUP_M") ? atoi(getenv("BSG_GEMM_GROUP_M")) : 0;
+  g.group_m = group_m;
   ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
   // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel

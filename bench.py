@@ -58,6 +58,21 @@ def cpu_baseline(geometry, threads: int) -> dict:
                       f"{dt:.1f} s, no warm-up"}
 
 
+def gemm_hbm_traffic_per_launch() -> float | None:
+    """HBM bytes per GEMM launch (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc
+    summary of this same command (`profiles/r1_step2_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
+    passes cannot run inside the timed process, so the figure is measured offline and reported here."""
+    f = ROOT / "profiles" / "r1_step2_pmc_summary.json"
+    if not f.exists():
+        return None
+    n = b = 0.0
+    for k, v in json.loads(f.read_text()).items():
+        if "gemm_nt_kernel" in k:
+            n += v["launches"]
+            b += v["launches"] * (v["hbm_fetch_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6
+    return round(b / n) if n else None
+
+
 def log(msg: str) -> None:
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -163,7 +178,9 @@ def main() -> None:
             "whole_step_tflops_per_gpu": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12, 1),
             "whole_step_frac_of_mfma_peak": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12 / peak, 4),
             "roofline": {"kernel": "gemm_nt_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 1),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": gemm_hbm_traffic_per_launch() if args.batch == 64 and args.dtype == "bf16" else None,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, offline pass)",
                          "avg_launch_ms": round(ms / max(n, 1), 4), "launches": n,
                          "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2)},
             "kernel_time_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
