@@ -284,3 +284,35 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
                     prompt_pixel_values=torch.from_numpy(rec["prompt_pixel_values"]).to(DEV),
                     prompt_masks=torch.from_numpy(rec["prompt_masks"]).to(DEV), feature_ensemble=True)
     assert relmax(out.pred_masks, rec["pred"]) < TOL[dtype]["t"]
+
+
+def test_wide_grid_and_wide_encoder_vs_oracle():
+    """BASELINE config 5 geometry class: 64 x 32 token grid (1024 x 512 canvas: no padded key slots, Hp = 64) and a
+    2048-wide encoder with 32 heads; 2 layers so the CPU oracle finishes in seconds.  No reference checkpoint of this
+    shape exists, so parity is against the oracle (itself pinned on the reference geometry)."""
+    import dataclasses
+
+    from beach_seg_amd.seggpt import SegGptNative
+
+    g = dataclasses.replace(SegGptGeometry.tiny(), hidden_size=2048, num_attention_heads=32, mlp_dim=4096,
+                            image_size=(1024, 512), pretrain_image_size=224, num_hidden_layers=2, merge_index=0,
+                            intermediate_hidden_state_indices=(0, 1))
+    _models.clear()
+    sd = synth_state_dict(g, seed=5)
+    model = SegGptNative(sd, g, device=DEV, dtype=torch.float32)
+    pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, 1, 9)
+    pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
+    lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
+    yes = (lb_cls != 0)[:, None]
+    p_ref = prm.clone().requires_grad_(True)
+    pred_ref = O.forward(sd, g, pix, p_ref, pm)
+    loss_ref = O.seggpt_loss(pred_ref, lab, yes, 0.01, "reference")
+    (grad_ref,) = torch.autograd.grad(loss_ref, p_ref)
+    p = prm.to(DEV).requires_grad_(True)
+    out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
+    loss = ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference")
+    loss.backward()
+    assert relmax(out.pred_masks, pred_ref) < 1e-4
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    assert relmax(p.grad, grad_ref) < 1e-4
+    del model
