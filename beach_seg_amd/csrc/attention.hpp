@@ -48,7 +48,13 @@ DEVI void attn_block_ids(int nx, int nh, int S, int& x, int& head, int& s) {
   s = t / nh;
 }
 
-template <int RB> DEVI int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : (row & 15); }
+// LDS chunk swizzle (position = chunk ^ swz(row)).  128-byte (bf16) rows are read two ways: along the row
+// (ds_read_b128, lane = row) and TRANSPOSED (ds_read_b64_tr_b16, four rows x 64 bytes per half-wave).  With
+// u = row >> 1, (u & 7) ^ ((u & 1) << 2) keeps both conflict-free: it is a bijection on the eight row pairs a
+// b128 phase touches, and rows r, r+2 of a transposed 4-row block land in different 64-byte bank groups.
+template <int RB> DEVI int swz(int row) {
+  return RB == 128 ? (((row >> 1) & 7) ^ (((row >> 1) & 1) << 2)) : (row & 15);
+}
 
 // token index of slot `kw` of grid row `gr` (clamped to a valid token: padded slots carry weight 0)
 DEVI int slot_token(int gr, int kw, int wp) { return gr * wp + (kw < wp ? kw : wp - 1); }
@@ -83,6 +89,21 @@ DEVI f32x4 lds_perm_chunk(const char* tile, int row, int b, int s, int h, float)
   const int c = 8 * b + 2 * s + h;
   return *(const f32x4*)(tile + row * 256 + ((c ^ swz<256>(row)) << 4));
 }
+// The same bf16 A operand fetched from the ROW-MAJOR [slot][64] tile with the gfx950 transposing
+// LDS read: per 16-lane group, ds_read_b64_tr_b16 takes a 4-row x 16-column block (lane 4q+p addresses row q,
+// columns 4p..4p+3) and hands lane i column i of the four rows.  Rows = slots 16s + 4h + {0..3} (+8 for the second
+// read), columns = d 32*db + 16*(group & 1) + i = this lane's A row.  No transposed copy in HBM, no permutation.
+typedef __attribute__((address_space(3))) bf16x4* lds_b4_ptr;
+DEVI bf16x8 lds_tr_chunk(const char* tile, int db, int b, int s, int lane) {
+  const int gi = lane >> 4, i = lane & 15, qd = i >> 2, p = i & 3, h = gi >> 1;
+  const int r0 = 32 * b + 16 * s + 4 * h + qd;
+  const int c = 4 * db + 2 * (gi & 1) + (p >> 1);
+  const char* a0 = tile + r0 * 128 + ((c ^ swz<128>(r0)) << 4) + 8 * (p & 1);
+  const char* a1 = tile + (r0 + 8) * 128 + ((c ^ swz<128>(r0 + 8)) << 4) + 8 * (p & 1);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(a1));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 // The matching B-operand chunk built from accumulator block `p` (already exponentiated / scaled).
 DEVI bf16x8 acc_chunk(const f32x16& p, int s, bf16_t) {
   bf16x8 c;
@@ -101,11 +122,12 @@ template <typename T> struct AttnK {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T>
+template <typename T, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT][TILE]
+  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
@@ -115,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const long sh = (long)s * a.nh + head;
   const int npad = a.hp * 32;
   const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
-  const char* vtbase = (const char*)a.vt + sh * 64 * npad * sizeof(T);
+  const char* vtbase = TR ? (const char*)a.v + ((long)s * a.N * a.ld + head * 64) * sizeof(T)
+                          : (const char*)a.vt + sh * 64 * npad * sizeof(T);
 
   // loop-invariant per-lane state
   Chunk qf[C::KS_D];
@@ -147,7 +170,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     dma_tile<T>(kt_l, wave, lane, [&](int r) {
       return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
     });
-    dma_tile<T>(vt_l, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
+    if constexpr (TR)
+      dma_tile<T>(vt_l, wave, lane, [&](int r) {
+        return vtbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+      });
+    else
+      dma_tile<T>(vt_l, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
   };
 
   f32x2 rh_next = *(const f32x2*)(relh_q);
@@ -210,7 +238,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int ks = 0; ks < C::KS_B; ++ks) {
         const Chunk pb = acc_chunk(st[b], ks, T());
 #pragma unroll
-        for (int db = 0; db < 2; ++db) mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+        for (int db = 0; db < 2; ++db) {
+          if constexpr (TR) mma32(o[db], lds_tr_chunk(vt_l, db, b, ks, lane), pb);
+          else mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+        }
       }
   }
   l += __shfl_xor(l, 32, 64);
@@ -368,11 +399,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
 // P^T = exp2(S^T c2 - lse2) -> dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.
 // The rel-pos gradients fall out of the layout: d relw[q][kw] accumulates per accumulator REGISTER over the
 // whole key loop (register <-> kw), d relh[q][2t+b] is the per-block sum.
-template <typename T>
+template <typename T, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT][TILE]
+  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  constexpr int NTILE = TR ? 2 : 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT (not TR)][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
@@ -431,14 +464,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
   const int nt = a.hp >> 1;
   auto issue = [&](int t, int buf) {
-    char* k_l = smem + buf * 3 * C::TILE;
+    char* k_l = smem + buf * NTILE * C::TILE;
     dma_tile<T>(k_l, wave, lane, [&](int r) {
       return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
     });
     dma_tile<T>(k_l + C::TILE, wave, lane, [&](int r) {
       return vbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
     });
-    dma_tile<T>(k_l + 2 * C::TILE, wave, lane, [&](int r) { return ktbase + ((long)r * npad + t * 64) * sizeof(T); });
+    if constexpr (!TR)
+      dma_tile<T>(k_l + 2 * C::TILE, wave, lane, [&](int r) { return ktbase + ((long)r * npad + t * 64) * sizeof(T); });
   };
 
   f32x2 rh_next = *(const f32x2*)(relh_q);
@@ -452,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
       issue(t + 1, buf ^ 1);
     }
-    const char* k_l = smem + buf * 3 * C::TILE;
+    const char* k_l = smem + buf * NTILE * C::TILE;
     const char* v_l = k_l + C::TILE;
-    const char* kt_l = k_l + 2 * C::TILE;
+    const char* kt_l = k_l + 2 * C::TILE;  // !TR only
     float drh[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -481,7 +515,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int ks = 0; ks < C::KS_B; ++ks) {
         const Chunk db_ = acc_chunk(st, ks, T());
 #pragma unroll
-        for (int d = 0; d < 2; ++d) mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
+        for (int d = 0; d < 2; ++d) {
+          if constexpr (TR) mma32(dqt[d], lds_tr_chunk(k_l, d, b, ks, lane), db_);
+          else mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
+        }
       }
     }
     if (h == 0 && q0 + col < a.N) *(f32x2*)(drelh_q + 2 * t) = f32x2{drh[0], drh[1]};
@@ -533,19 +570,21 @@ DEVI void dma_rows(char* lds_tile, int wave, int lane, RowSrc row_src) {
   }
 }
 
-template <typename T> struct DkvK {
+template <typename T, bool TR> struct DkvK {
   static constexpr int TILE = AttnK<T>::TILE;
-  static constexpr int STAGE = 4 * TILE + 8192 + 4096;  // Q | dO | QT | dOT | relwT [32][64 f32] | stats [16][64 f32]
+  static constexpr int NTILE = TR ? 2 : 4;
+  static constexpr int STAGE = NTILE * TILE + 8192 + 4096;  // Q | dO | (QT | dOT) | relwT [32][64 f32] | stats [16][64 f32]
 };
 
 // Eight waves per workgroup, each owning ONE grid row of keys (32 slots): dK^T, dV^T of that row stay in 64
 // accumulator registers, so two waves fit per SIMD.  The per-query statistics (lse2, delta, rel-pos rows) ride the
 // same LDS-DMA stream as the Q / dO tiles instead of occupying 128 registers.
-template <typename T>
+template <typename T, bool TR>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  constexpr int RB = C::RB, STAGE = DkvK<T>::STAGE;
+  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  constexpr int RB = C::RB, STAGE = DkvK<T, TR>::STAGE, NTILE = DkvK<T, TR>::NTILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -587,14 +626,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
     dma_rows<RB, 64, 8, true>(base + C::TILE, wave, lane, [&](int r) {
       return dobase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ldo * sizeof(T);
     });
-    dma_rows<RB, 64, 8, true>(base + 2 * C::TILE, wave, lane,
-                              [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
-    dma_rows<RB, 64, 8, true>(base + 3 * C::TILE, wave, lane,
-                              [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
-    dma_rows<256, 32, 8, true>(base + 4 * C::TILE, wave, lane, [&](int r) {
+    if constexpr (!TR) {
+      dma_rows<RB, 64, 8, true>(base + 2 * C::TILE, wave, lane,
+                                [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
+      dma_rows<RB, 64, 8, true>(base + 3 * C::TILE, wave, lane,
+                                [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
+    }
+    dma_rows<256, 32, 8, true>(base + NTILE * C::TILE, wave, lane, [&](int r) {
       return (const char*)(a.relwT + (sh * 32 + r) * npad + t * 64);
     });
-    dma_rows<256, 16, 8, false>(base + 4 * C::TILE + 8192, wave, lane, [&](int r) {
+    dma_rows<256, 16, 8, false>(base + NTILE * C::TILE + 8192, wave, lane, [&](int r) {
       const float* p = r == 0 ? a.lse2 + sh * npad
                      : r == 1 ? a.delta + sh * npad
                               : a.relhT + (sh * a.hp + min(kr0 + max(r - 2, 0), a.hp - 1)) * npad;
@@ -610,10 +651,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
     if (t + 1 < nt) issue(t + 1, buf ^ 1);
     const char* q_l = smem + buf * STAGE;
     const char* do_l = q_l + C::TILE;
-    const char* qt_l = q_l + 2 * C::TILE;
-    const char* dot_l = q_l + 3 * C::TILE;
-    const char* rw_l = q_l + 4 * C::TILE + col * 256;
-    const char* st_l = q_l + 4 * C::TILE + 8192;
+    const char* qt_l = q_l + 2 * C::TILE;   // !TR only
+    const char* dot_l = q_l + 3 * C::TILE;  // !TR only
+    const char* rw_l = q_l + NTILE * C::TILE + col * 256;
+    const char* st_l = q_l + NTILE * C::TILE + 8192;
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
       f32x16 st, dp;
@@ -646,8 +687,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
         const Chunk dsb = acc_chunk(dp, ks, T());
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          mma32(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
-          mma32(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
+          if constexpr (TR) {
+            mma32(dvt[d], lds_tr_chunk(do_l, d, qa, ks, lane), pb);
+            mma32(dkt[d], lds_tr_chunk(q_l, d, qa, ks, lane), dsb);
+          } else {
+            mma32(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
+            mma32(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
+          }
         }
       }
     }

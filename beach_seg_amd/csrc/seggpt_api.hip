@@ -257,22 +257,33 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
         hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, S), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
-      const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N, hp,
-                         wp, nh, hb);
-      CHECK_LAUNCH();
+      // bf16: the PV operand comes straight from the row-major V tile through transposing LDS reads; f32 (no
+      // 32-bit transposing read on gfx950) keeps the row-padded V^T copy.
+      static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
+      constexpr bool can_tr = sizeof(T) == 2;
+      const bool tr = can_tr && tr_env;
+      if (!tr) {
+        const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N,
+                           hp, wp, nh, hb);
+        CHECK_LAUNCH();
+      }
       AttnArgs a{};
-      a.q = qkv; a.k = qkv + D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o; a.ldo = D;
-      a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o;
+      a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
       static const bool piped = getenv("BSG_ATTN_FWD_PIPE") != nullptr;  // software-pipelined variant: measured 3 % slower (2 waves/SIMD)
-      static bool once2 = (allow_lds(attn_fwd_kernel<T>, 160 * 1024), allow_lds(attn_fwd_pipe_kernel<T>, 160 * 1024), true);
+      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024),
+                           allow_lds(attn_fwd_pipe_kernel<T>, 160 * 1024), true);
       (void)once2;
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
-      if (piped)
-        hipLaunchKernelGGL((attn_fwd_pipe_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), 5 * AttnK<T>::TILE + ldspad, st, a);
+      const dim3 agrid(((N + 127) / 128) * nh * S);
+      if (piped && !tr)
+        hipLaunchKernelGGL((attn_fwd_pipe_kernel<T>), agrid, dim3(256), 5 * AttnK<T>::TILE + ldspad, st, a);
+      else if (tr)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
       else
-        hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(((N + 127) / 128) * nh * S), dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
       CHECK_LAUNCH();
     }
     {
@@ -458,21 +469,29 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, r);
         CHECK_LAUNCH();
       }
-      const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh, hb);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh, hb);
-      hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
-                         nh, hb);
-      CHECK_LAUNCH();
+      static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
+      constexpr bool can_tr = sizeof(T) == 2;  // bf16: K^T / Q^T / dO^T operands via transposing LDS reads of the row-major tiles
+      const bool tr = can_tr && tr_env;
+      if (!tr) {
+        const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh, hb);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh, hb);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
+                           nh, hb);
+        CHECK_LAUNCH();
+      }
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.relh = relh;
       a.relw = relw; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv; a.drelh = drelh; a.drelw = drelw;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static bool once = (allow_lds(attn_bwd_dq_kernel<T>, 6 * AttnK<T>::TILE), true);
+      static bool once = (allow_lds(attn_bwd_dq_kernel<T, false>, 6 * AttnK<T>::TILE),
+                          allow_lds(attn_bwd_dq_kernel<T, can_tr>, 6 * AttnK<T>::TILE), true);
       (void)once;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(((N + 127) / 128) * nh * B), dim3(256), 6 * AttnK<T>::TILE, st, a);
+        const dim3 qgrid(((N + 127) / 128) * nh * B);
+        if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, can_tr>), qgrid, dim3(256), 4 * AttnK<T>::TILE, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false>), qgrid, dim3(256), 6 * AttnK<T>::TILE, st, a);
       }
       CHECK_LAUNCH();
       {
@@ -486,11 +505,15 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
-      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T>, 2 * DkvK<T>::STAGE), true);
+      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, false>, 2 * DkvK<T, false>::STAGE),
+                           allow_lds(attn_bwd_dkv_kernel<T, can_tr>, 2 * DkvK<T, can_tr>::STAGE), true);
       (void)once2;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(((hp + 7) / 8) * nh * B), dim3(512), 2 * DkvK<T>::STAGE, st, k);
+        const dim3 kgrid(((hp + 7) / 8) * nh * B);
+        constexpr int lds_tr = 2 * DkvK<T, can_tr>::STAGE, lds_t = 2 * DkvK<T, false>::STAGE;
+        if (tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, can_tr>), kgrid, dim3(512), lds_tr, st, k);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false>), kgrid, dim3(512), lds_t, st, k);
       }
       CHECK_LAUNCH();
     }
