@@ -12,6 +12,9 @@
 // the O^T rescale are lane-local, and the S^T accumulator is directly the B operand of O^T += V^T P^T.
 #pragma once
 #include "common.hpp"
+#ifndef BSG_DIAG_DQ
+#define BSG_DIAG_DQ 0  // timing-only ablations of the dQ kernel (wrong results): 1 no softmax VALU, 2 no MFMA, 3 no LDS reads, 4 no DMA/barrier
+#endif
 
 struct AttnArgs {
   const void* q;   // T [S*N][ld] (+ column offset applied by caller) ; head h at columns h*64..
@@ -23,8 +26,8 @@ struct AttnArgs {
   const void* qt;  // backward
   const void* dot; // backward: dO^T
   const void* dout;  // backward: dO, T [S*N][ldo]
-  const float* relh;  // [S][nh][N][Hp]   (already divided by scale)
-  const float* relw;  // [S][nh][N][32]
+  const void* rel_cat;   // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2 Hp)..
+  const void* rel_catT;  // backward: T [64][LH + LW]
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
   float* lse2;        // [S][nh][Hp*32] (row-padded)  log2-domain logsumexp of the logits
@@ -32,9 +35,8 @@ struct AttnArgs {
   void* dq;  // backward outputs, T [S*N][ld] at the q/k/v column offsets of the dqkv buffer
   void* dk;
   void* dv;
-  float* drelh;  // [S][nh][N][Hp]   d logits / d relh (unscaled)
-  float* drelw;  // [S][nh][N][32]
   int S, nh, N, hp, wp;
+  int prio;  // experiment: wave priority pattern (0 = none)
   float scale;
 };
 
@@ -46,6 +48,22 @@ DEVI void attn_block_ids(int nx, int nh, int S, int& x, int& head, int& s) {
   const int t = lid / nx;
   head = t % nh;
   s = t / nh;
+}
+
+
+// experiment knob: give co-resident waves different issue priority so they de-phase (one in its MFMA segment
+// while the other is in softmax VALU) instead of convoying through both at half speed.
+DEVI void attn_set_prio(int mode, int wave) {
+  const int b = blockIdx.x;
+  int p = 0;
+  if (mode == 1) p = b & 1;
+  else if (mode == 2) p = (b >> 3) & 1;
+  else if (mode == 3) p = (b >> 8) & 1;
+  else if (mode == 4) p = wave >= 4;
+  else if (mode == 5) p = (b >> 3) & 3;
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 3) __builtin_amdgcn_s_setprio(3);
 }
 
 // LDS chunk swizzle (position = chunk ^ swz(row)).  128-byte (bf16) rows are read two ways: along the row
@@ -121,17 +139,132 @@ template <typename T> struct AttnK {
   static constexpr int TILE = 64 * RB;
 };
 
+
+// ------------------------------------------------------------------------- decomposed rel-pos bias, in-kernel
+// relh[q][kh] = q . rel_pos_h[qh - kh + Hp - 1] / scale,  relw[q][kw] = q . rel_pos_w[qw - kw + Wp - 1] / scale
+// (unscaled q, HF:268-311, HF:326-329) for the 32 queries of one wave, from the Q fragments the wave already
+// holds: G^T[rel][q] = rel_cat[rel] . q on MFMA (lane = query, register = rel row), then the per-query shift
+// goes through LDS.  relh lands in a per-wave table [32][HS] that stays resident for the key loop; relw is
+// returned as the loop-invariant accumulator-init vector (-inf on padded key slots: no masking anywhere).
+DEVI int relh_stride(int hp) { return hp | 1; }  // odd: lane-per-row accesses are conflict-free
+
+template <typename T>
+DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int wp, int qh, int qw,
+                             float alpha, float* scratch_w /* 32 x 64 floats */, float* table_h /* 32 x HS */,
+                             f32x16& rwv, int lane) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  const int h = lane >> 5, col = lane & 31;
+  const int HS = relh_stride(hp), nrelh = 2 * hp - 1, nrelw = 2 * wp - 1, LH = (2 * hp + 15) & ~15;
+  const char* rc = (const char*)rel_cat + h * 16;  // chunk 2 ks + h of a 128-byte row
+  // Groups of up to four 32-row blocks of the table: all A chunks are fetched (L2) before the first MFMA, rows past
+  // the table are clamped and their results land in the spare slot `hp` of the row (no exec juggling per store).
+  for (int blk0 = 0; blk0 * 32 < nrelh; blk0 += 4) {
+    Chunk af[4][C::KS_D];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = min((blk0 + i) * 32 + col, nrelh - 1);
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) af[i][ks] = *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + ks * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) mma32(acc, af[i][ks], qf[ks]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kh = qh + hp - 1 - ((blk0 + i) * 32 + acc32_row(r, h));
+        table_h[col * HS + ((unsigned)kh < (unsigned)hp ? kh : hp)] = acc[r] * alpha;
+      }
+    }
+  }
+  {  // w part: 2 wp - 1 <= 63 rows
+    Chunk af[2][C::KS_D];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rr = LH + min(i * 32 + col, nrelw - 1);
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) af[i][ks] = *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + ks * 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) mma32(acc, af[i][ks], qf[ks]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rel = i * 32 + acc32_row(r, h);  // < 64: column rotated by the row keeps both accesses spread
+        scratch_w[col * 64 + ((rel + col) & 63)] = acc[r] * alpha;
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): single-wave image
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int kw = acc32_row(r, h);
+    const float v = scratch_w[col * 64 + ((qw + wp - 1 - min(kw, wp - 1) + col) & 63)];
+    rwv[r] = kw < wp ? v : -INFINITY;
+  }
+}
+
+// Backward of the above into dq: acc[blk][.] (d = 32 blk + ..., lane = query) = sum_rel rel_catT[d][rel] X[rel][q],
+// X[rel][q] = drel[q][pos + size - 1 - rel] gathered per lane from the per-wave LDS images of d relh / d relw.
+template <typename T>
+DEVI void relpos_wave_bwd(f32x16 (&acc)[2], const void* rel_catT, int hp, int wp, int qh, int qw, const float* table_h,
+                          const float* image_w /* 32 x 33 */, int lane) {
+  typedef typename Traits<T>::Chunk Chunk;
+  constexpr int EPC = Traits<T>::EPC, KG = 4;  // k-steps whose A chunks are fetched together
+  const int h = lane >> 5, col = lane & 31;
+  const int HS = relh_stride(hp), LH = (2 * hp + 15) & ~15, LW = (2 * wp + 15) & ~15, RC = LH + LW;
+  const char* rt = (const char*)rel_catT;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  for (int part = 0; part < 2; ++part) {
+    const int len = part == 0 ? LH : LW, size = part == 0 ? hp : wp, pos = part == 0 ? qh : qw;
+    const float* src = part == 0 ? table_h + col * HS : image_w + col * 33;
+    const int cbase = part == 0 ? 0 : LH, nks = len / (2 * EPC);
+    for (int ks0 = 0; ks0 < nks; ks0 += KG) {
+      Chunk af[KG][2], bf[KG];
+#pragma unroll
+      for (int i = 0; i < KG; ++i) {
+        const int r0 = (2 * min(ks0 + i, nks - 1) + h) * EPC;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+          af[i][blk] = *(const Chunk*)(rt + ((long)(32 * blk + col) * RC + cbase + r0) * sizeof(T));
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const int k = pos + size - 1 - (r0 + j);
+          const bool ok = (unsigned)k < (unsigned)size && ks0 + i < nks;
+          const float v = src[ok ? k : 0];
+          bf[i][j] = from_f32<T>(ok ? v : 0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < KG; ++i)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) mma32(acc[blk], af[i][blk], bf[i]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE] | relh tables [4][32][HS]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
+  attn_set_prio(a.prio, wave);
   const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const long sh = (long)s * a.nh + head;
@@ -147,16 +280,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
   }
+  // rel-pos bias of this wave's 32 queries (tile area doubles as the shear scratch before the first DMA)
   f32x16 rwv;
-  {
-    const float* p = a.relw + (sh * a.N + q) * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
-      rwv[4 * i] = v[0]; rwv[4 * i + 1] = v[1]; rwv[4 * i + 2] = v[2]; rwv[4 * i + 3] = v[3];
-    }
-  }
-  const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
+  float* relh_q = (float*)(smem + 4 * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
+  relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, 1.0f / a.scale, (float*)(smem + wave * 8192),
+                        relh_q - col * relh_stride(a.hp), rwv, lane);
+  __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   float m = -INFINITY, l = 0.f;
   f32x16 o[2];
@@ -178,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       dma_tile<T>(vt_l, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
   };
 
-  f32x2 rh_next = *(const f32x2*)(relh_q);
+  f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -186,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     wait_vm0();
     __syncthreads();
     if (t + 1 < nt) {
-      rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
+      rh_next = f32x2{relh_q[2 * t + 2], relh_q[2 * t + 3]};
       issue(t + 1, buf ^ 1);
     }
     const char* kt_l = smem + buf * 2 * C::TILE;
@@ -258,142 +387,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------- forward, software-pipelined
-// At head_dim 64 one score costs 256 MFMA flops and one v_exp_f32, and the transcendental is the scarcer resource
-// (measured: removing the 32 exps per tile takes 41 % off the kernel above).  So the S^T MFMAs of tile t+1 are
-// issued in the same basic block as the softmax of tile t (no dependency between them): the matrix pipe works
-// under the exp/VALU stream of the same wave instead of waiting for it.  K tiles run two ahead (3-deep ring),
-// V^T one ahead (2-deep).
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
-  typedef typename Traits<T>::Chunk Chunk;
-  typedef AttnK<T> C;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [3][TILE] | VT ring [2][TILE]
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bx, head, s;
-  attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
-  const int q0 = bx * 128 + wave * 32;
-  const int q = min(q0 + col, a.N - 1);
-  const long sh = (long)s * a.nh + head;
-  const int npad = a.hp * 32;
-  const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
-  const char* vtbase = (const char*)a.vt + sh * 64 * npad * sizeof(T);
-  char* kring = smem;
-  char* vring = smem + 3 * C::TILE;
-
-  Chunk qf[C::KS_D];
-  {
-    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
-#pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
-  }
-  f32x16 rwv;
-  {
-    const float* p = a.relw + (sh * a.N + q) * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
-      rwv[4 * i] = v[0]; rwv[4 * i + 1] = v[1]; rwv[4 * i + 2] = v[2]; rwv[4 * i + 3] = v[3];
-    }
-  }
-  const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
-  const float c2 = a.scale * 1.44269504088896340736f;
-  float m = -INFINITY, l = 0.f;
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-  const int nt = a.hp >> 1;
-
-  auto issue_k = [&](int t) {
-    dma_tile<T>(kring + (t % 3) * C::TILE, wave, lane, [&](int r) {
-      return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
-    });
-  };
-  auto issue_v = [&](int t) {
-    dma_tile<T>(vring + (t & 1) * C::TILE, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
-  };
-  auto qk = [&](int t, f32x16 (&st)[2]) {
-    const char* kt_l = kring + (t % 3) * C::TILE;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      st[b] = rwv;
-#pragma unroll
-      for (int ks = 0; ks < C::KS_D; ++ks) mma32(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qf[ks]);
-    }
-  };
-
-  f32x16 sc[2], sn[2];
-  issue_k(0);
-  issue_v(0);
-  if (nt > 1) issue_k(1);
-  wait_vm0();
-  __syncthreads();
-  qk(0, sc);
-  f32x2 rh = *(const f32x2*)(relh_q);
-  for (int t = 0; t < nt; ++t) {
-    f32x2 rh_next = rh;
-    if (t > 0) {  // K(t+1) and VT(t) were issued one iteration ago
-      wait_vm0();
-      __syncthreads();
-    }
-    if (t + 1 < nt) rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
-    if (t + 2 < nt) issue_k(t + 2);
-    if (t + 1 < nt) issue_v(t + 1);
-    if (t + 1 < nt) qk(t + 1, sn);  // independent of the softmax below: overlaps it
-    // ---- softmax of tile t
-    float mx0 = sc[0][0], mx1 = sc[1][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, sc[0][r]); mx1 = fmaxf(mx1, sc[1][r]); }
-    float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    if (__builtin_amdgcn_ballot_w64(mn > m)) {
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
-      l *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-      m = mn;
-    }
-    const float nb0 = (rh[0] - m) * c2, nb1 = (rh[1] - m) * c2;
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[0][r], c2, nb0));
-      const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[1][r], c2, nb1));
-      sc[0][r] = p0;
-      sc[1][r] = p1;
-      ps += p0 + p1;
-    }
-    l += ps;
-    // ---- O^T += V^T P^T
-    const char* vt_l = vring + (t & 1) * C::TILE;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int ks = 0; ks < C::KS_B; ++ks) {
-        const Chunk pb = acc_chunk(sc[b], ks, T());
-#pragma unroll
-        for (int db = 0; db < 2; ++db) mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
-      }
-    sc[0] = sn[0];
-    sc[1] = sn[1];
-    rh = rh_next;
-  }
-  l += __shfl_xor(l, 32, 64);
-  if (q0 + col < a.N) {
-    const float inv = 1.f / l;
-    T* orow = (T*)a.out + ((long)s * a.N + q) * a.ldo + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *(typename Traits<T>::Vec4*)(orow + 32 * db + 8 * i + 4 * h) =
-            pack4<T>(o[db][4 * i] * inv, o[db][4 * i + 1] * inv, o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
-    if (h == 0 && a.lse2) a.lse2[sh * npad + (q / a.wp) * 32 + (q % a.wp)] = m * c2 + log2f(l);
-  }
-}
-
 // ------------------------------------------------------------------------------------------- backward: dQ
 // Query-stationary, same swapped layout as forward.  Per key tile: S^T (bias as initial accumulator) ->
 // P^T = exp2(S^T c2 - lse2) -> dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.
@@ -405,11 +398,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   typedef AttnK<T> C;
   static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
   constexpr int NTILE = TR ? 2 : 3;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT (not TR)][TILE]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT (not TR)][TILE] | relh tables [4][32][HS]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
+  attn_set_prio(a.prio, wave);
   const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const int qpad = (q / a.wp) * 32 + (q % a.wp);
@@ -429,20 +423,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       dof[ks] = *(const Chunk*)(drow + (2 * ks + h) * 16);
     }
   }
+  // rel-pos bias of this wave's queries, computed in-kernel; d relh overwrites the relh table entry by entry
   f32x16 rwv;
   float drw[16];
-  {
-    const float* p = a.relw + (sh * a.N + q) * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 v = *(const f32x4*)(p + 8 * i + 4 * h);
-      rwv[4 * i] = v[0]; rwv[4 * i + 1] = v[1]; rwv[4 * i + 2] = v[2]; rwv[4 * i + 3] = v[3];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) drw[i] = 0.f;
-  }
-  const float* relh_q = a.relh + (sh * a.N + q) * a.hp;
-  float* drelh_q = a.drelh + (sh * a.N + q) * a.hp;
+  for (int i = 0; i < 16; ++i) drw[i] = 0.f;
+  const int qh = q / a.wp, qw = q % a.wp;
+  float* relh_q = (float*)(smem + 2 * NTILE * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
+  relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, qh, qw, 1.0f / a.scale, (float*)(smem + wave * 8192),
+                        relh_q - col * relh_stride(a.hp), rwv, lane);
+  __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   const float lse = a.lse2[sh * npad + qpad];
   // delta[q] = sum_d dO[q][d] O[q][d]: each half-wave lane holds half of the row; published for the dK/dV kernel
@@ -475,17 +465,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       dma_tile<T>(k_l + 2 * C::TILE, wave, lane, [&](int r) { return ktbase + ((long)r * npad + t * 64) * sizeof(T); });
   };
 
-  f32x2 rh_next = *(const f32x2*)(relh_q);
+  f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     const f32x2 rh = rh_next;
+#if BSG_DIAG_DQ == 4
+    if (t == 0) { wait_vm0(); __syncthreads(); }
+    if (t + 1 < nt) rh_next = f32x2{relh_q[2 * t + 2], relh_q[2 * t + 3]};
+#else
     wait_vm0();
     __syncthreads();
     if (t + 1 < nt) {
-      rh_next = *(const f32x2*)(relh_q + 2 * (t + 1));
+      rh_next = f32x2{relh_q[2 * t + 2], relh_q[2 * t + 3]};
       issue(t + 1, buf ^ 1);
     }
+#endif
     const char* k_l = smem + buf * NTILE * C::TILE;
     const char* v_l = k_l + C::TILE;
     const char* kt_l = k_l + 2 * C::TILE;  // !TR only
@@ -497,18 +492,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
+#if BSG_DIAG_DQ == 3
+        mma32(st, dof[(ks + b) & 3], qf[ks]);
+        mma32(dp, qf[(ks + b) & 3], dof[ks]);
+#elif BSG_DIAG_DQ == 2
+        st[ks] += to_f32(lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h)[0]);
+        dp[ks] += to_f32(lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h)[0]);
+#else
         mma32(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qf[ks]);
         mma32(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dof[ks]);
+#endif
       }
       const float nb = fmaf(rh[b], c2, -lse);
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+#if BSG_DIAG_DQ == 1
+        const float ds = st[r] + dp[r];
+        st[r] = ds;
+        sum = nb;
+#else
         const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, nb));  // 0 on padded key slots (bias -inf)
         const float ds = p * (dp[r] - dl);
         st[r] = ds;
         drw[r] += ds;
         sum += ds;
+#endif
       }
       drh[b] = sum + __shfl_xor(sum, 32, 64);
 #pragma unroll
@@ -516,13 +525,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const Chunk db_ = acc_chunk(st, ks, T());
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
+#if BSG_DIAG_DQ == 3
+          if constexpr (TR) mma32(dqt[d], qf[(ks + d) & 3], db_);
+#elif BSG_DIAG_DQ == 2
+          if constexpr (TR) dqt[d][ks] += to_f32(lds_tr_chunk(k_l, d, b, ks, lane)[0]) * to_f32(db_[0]);
+#else
           if constexpr (TR) mma32(dqt[d], lds_tr_chunk(k_l, d, b, ks, lane), db_);
+#endif
           else mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
         }
       }
     }
-    if (h == 0 && q0 + col < a.N) *(f32x2*)(drelh_q + 2 * t) = f32x2{drh[0], drh[1]};
+    if (h == 0) { relh_q[2 * t] = drh[0]; relh_q[2 * t + 1] = drh[1]; }  // both were read a tile ago
   }
+  // rel-pos gradient straight into dq: d relw goes to a [32][33] image in this wave's slice of the (now idle) tile area
+  __syncthreads();
+  float* image_w = (float*)(smem + wave * 8192);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) image_w[col * 33 + acc32_row(r, h)] = drw[r];
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  f32x16 racc[2];
+  relpos_wave_bwd<T>(racc, a.rel_catT, a.hp, a.wp, qh, qw, relh_q - col * relh_stride(a.hp), image_w, lane);
   if (q0 + col < a.N) {
     T* orow = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
 #pragma unroll
@@ -530,12 +554,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         *(typename Traits<T>::Vec4*)(orow + 32 * d + 8 * i + 4 * h) =
-            pack4<T>(dqt[d][4 * i] * a.scale, dqt[d][4 * i + 1] * a.scale, dqt[d][4 * i + 2] * a.scale,
-                     dqt[d][4 * i + 3] * a.scale);
-    float* p = a.drelw + (sh * a.N + q) * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *(f32x4*)(p + 8 * i + 4 * h) = f32x4{drw[4 * i], drw[4 * i + 1], drw[4 * i + 2], drw[4 * i + 3]};
+            pack4<T>(fmaf(dqt[d][4 * i], a.scale, racc[d][4 * i]), fmaf(dqt[d][4 * i + 1], a.scale, racc[d][4 * i + 1]),
+                     fmaf(dqt[d][4 * i + 2], a.scale, racc[d][4 * i + 2]), fmaf(dqt[d][4 * i + 3], a.scale, racc[d][4 * i + 3]));
   }
 }
 
@@ -552,6 +572,7 @@ struct AttnBwdKvArgs {
   const float* relwT; const float* relhT; const float* lse2; const float* delta;
   void* dk; void* dv;  // T, row stride ld
   int S, nh, N, hp, wp;
+  int prio;
   float scale;
 };
 
@@ -590,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
+  attn_set_prio(a.prio, wave);
   const int nt = a.hp >> 1;
   const int kr0 = bx * 8;
   const bool wave_valid = kr0 + wave < a.hp;
@@ -726,8 +748,8 @@ struct RelTabArgs {
   const void* q;  // T [S*N][ld], head h at columns h*64
   long ld;
   const void* rel_cat;  // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2hp).., zeros elsewhere
-  float* relh;   // [S][nh][N][hp]
-  float* relw;   // [S][nh][N][32]
+  float* relh;   // [S][nh][N][hp] or null (the attention kernels compute their own; kept for tests / f32 debugging)
+  float* relw;   // [S][nh][N][32] or null
   float* relhT;  // [S][nh][hp][hp*32] or null
   float* relwT;  // [S][nh][32][hp*32] or null
   int S, nh, N, hp, wp;
@@ -772,7 +794,7 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
       const int kh0 = blk * 32 + 8 * i + 4 * h;
       if (kh0 < a.hp) {
         const f32x4 v = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]} * a.alpha;
-        if (qvalid) *(f32x4*)(a.relh + (sh * a.N + q) * a.hp + kh0) = v;
+        if (qvalid && a.relh) *(f32x4*)(a.relh + (sh * a.N + q) * a.hp + kh0) = v;
         if (a.relhT) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) a.relhT[(sh * a.hp + kh0 + j) * npad + qh * 32 + col] = v[j];
@@ -800,7 +822,7 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
   __builtin_amdgcn_wave_barrier();
   // relw[q][kw]: lane = kw, 16 queries per half-wave -> 128-byte coalesced rows
   // padded key slots (kw >= wp) and padded query slots get -inf: the attention kernels need no masking
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < 16 && a.relw; ++j) {
     const int qs = h * 16 + j;
     if (qs < a.wp)
       a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = col < a.wp ? g[qs * 65 + qs + a.wp - 1 - col] : -INFINITY;
@@ -809,94 +831,5 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
     for (int kw = h; kw < 32; kw += 2)
       a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] =
           (qvalid && kw < a.wp) ? g[col * 65 + col + a.wp - 1 - min(kw, a.wp - 1)] : -INFINITY;
-  }
-}
-
-
-// ------------------------------------------------------------------------ rel-pos gradient into dq (MFMA)
-// dq[q][c] += sum_kh drelh[q][kh] rel_pos_h[qh+Hp-1-kh][c] + sum_kw drelw[q][kw] rel_pos_w[qw+Wp-1-kw][c]
-// One wave per grid row of queries; the contraction runs over the REL index r (so the A operand is the
-// transposed table rel_catT[c][r], read in aligned chunks) and the B operand X[r][q] = drel[q][q_pos + size-1 - r]
-// is gathered per lane with bounds predicates.
-struct RelBwdArgs {
-  void* dq;  // T [S*N][ld], head h at columns h*64 (read-modify-write)
-  long ld;
-  const void* rel_catT;  // T [64][LH + LW]
-  const float* drelh;    // [S][nh][N][hp]
-  const float* drelw;    // [S][nh][N][32]
-  int S, nh, N, hp, wp;
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_bwd_mfma_kernel(RelBwdArgs a) {
-  typedef typename Traits<T>::Chunk Chunk;
-  constexpr int EPC = Traits<T>::EPC;
-  // per wave: the grid row's drelh block [wp][hp] and drelw block [wp][32] are CONTIGUOUS in HBM: stage them with
-  // 16-byte loads into padded LDS images (row strides hp+1 / 33 floats: conflict-free per-lane gathers)
-  __shared__ float sm[4][32 * 65 + 32 * 33];
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, s = blockIdx.z;
-  const int qh = blockIdx.x * 4 + wave;
-  if (qh >= a.hp) return;
-  const long sh = (long)s * a.nh + head;
-  const int LH = (2 * a.hp + 15) & ~15, LW = (2 * a.wp + 15) & ~15, RC = LH + LW;
-  const bool qvalid = col < a.wp;
-  const long q0 = (long)qh * a.wp;
-  float* lh = sm[wave];
-  float* lw = lh + 32 * 65;
-  {
-    const float* gh = a.drelh + (sh * a.N + q0) * a.hp;  // wp * hp floats
-    const int nh4 = a.wp * a.hp / 4;
-    for (int i = lane; i < nh4; i += 64) {
-      const f32x4 v = *(const f32x4*)(gh + 4 * i);
-      const int e = 4 * i, r = e / a.hp, c = e % a.hp;  // hp % 4 == 0: a chunk never straddles rows
-      float* d = lh + r * (a.hp + 1) + c;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-    const float* gw = a.drelw + (sh * a.N + q0) * 32;  // wp * 32 floats
-    for (int i = lane; i < a.wp * 8; i += 64) {
-      const f32x4 v = *(const f32x4*)(gw + 4 * i);
-      float* d = lw + (i >> 3) * 33 + 4 * (i & 7);
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_wave_barrier();
-  const char* rt = (const char*)a.rel_catT;
-  f32x16 acc[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-  const int qc = qvalid ? col : 0;
-  for (int part = 0; part < 2; ++part) {
-    const int len = part == 0 ? LH : LW, size = part == 0 ? a.hp : a.wp, pos = part == 0 ? qh : col;
-    const float* src = part == 0 ? lh + qc * (a.hp + 1) : lw + qc * 33;
-    const int cbase = part == 0 ? 0 : LH;
-    for (int ks = 0; ks < len / (2 * EPC); ++ks) {
-      const int r0 = (2 * ks + h) * EPC;
-      Chunk b;
-#pragma unroll
-      for (int j = 0; j < EPC; ++j) {
-        const int k = pos + size - 1 - (r0 + j);
-        const bool ok = qvalid && k >= 0 && k < size;
-        const float v = src[ok ? k : 0];
-        b[j] = from_f32<T>(ok ? v : 0.f);
-      }
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-        mma32(acc[blk], *(const Chunk*)(rt + ((long)(32 * blk + col) * RC + cbase + r0) * sizeof(T)), b);
-    }
-  }
-  if (qvalid) {
-    T* row = (T*)a.dq + ((long)s * a.N + q0 + col) * a.ld + head * 64;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        typename Traits<T>::Vec4* p = (typename Traits<T>::Vec4*)(row + 32 * blk + 8 * i + 4 * h);
-        const typename Traits<T>::Vec4 o = *p;
-        *p = pack4<T>(to_f32(o[0]) + acc[blk][4 * i], to_f32(o[1]) + acc[blk][4 * i + 1],
-                      to_f32(o[2]) + acc[blk][4 * i + 2], to_f32(o[3]) + acc[blk][4 * i + 3]);
-      }
   }
 }

@@ -102,8 +102,6 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
   p.add("ln_out", -1, r2 * D * es);
   p.add("h_act", -1, r2 * mlp * es);
   p.add("vt", -1, 2 * (size_t)B * nh * 64 * npad * es);
-  p.add("relh", -1, 2 * (size_t)B * nh * N * hp * 4);
-  p.add("relw", -1, 2 * (size_t)B * nh * N * 32 * 4);
   p.add("taps", -1, r1 * nt * D * es);
   p.add("feat", -1, (size_t)B * HW * 64 * es);
   if (train) {
@@ -119,8 +117,6 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     p.add("qt", -1, (size_t)B * nh * 64 * npad * es);
     p.add("dot", -1, (size_t)B * nh * 64 * npad * es);
     p.add("delta", -1, (size_t)B * nh * npad * 4);
-    p.add("drelh", -1, (size_t)B * nh * N * hp * 4);
-    p.add("drelw", -1, (size_t)B * nh * N * 32 * 4);
     p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
     p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
   }
@@ -213,8 +209,6 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   T* ln_out = c.template at<T>("ln_out");
   T* h_act = c.template at<T>("h_act");
   T* vt = c.template at<T>("vt");
-  float* relh = c.template at<float>("relh");
-  float* relw = c.template at<float>("relw");
   T* taps = c.template at<T>("taps");
   T* feat = c.template at<T>("feat");
 
@@ -250,13 +244,6 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       CHECK_LAUNCH();
     }
     {
-      {
-        RelTabArgs r{};
-        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relh = relh; r.relw = relw; r.S = S; r.nh = nh; r.N = N;
-        r.hp = hp; r.wp = wp; r.alpha = 1.0f / scale;
-        hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, S), dim3(256), 0, st, r);
-        CHECK_LAUNCH();
-      }
       // bf16: the PV operand comes straight from the row-major V tile through transposing LDS reads; f32 (no
       // 32-bit transposing read on gfx950) keeps the row-padded V^T copy.
       static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
@@ -269,21 +256,20 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
         CHECK_LAUNCH();
       }
       AttnArgs a{};
-      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.relh = relh; a.relw = relw; a.out = attn_o;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.out = attn_o;
       a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
+      static const int fprio = getenv("BSG_ATTN_PRIO_FWD") ? atoi(getenv("BSG_ATTN_PRIO_FWD")) : 0;
+      a.prio = fprio;
       static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
-      static const bool piped = getenv("BSG_ATTN_FWD_PIPE") != nullptr;  // software-pipelined variant: measured 3 % slower (2 waves/SIMD)
-      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024),
-                           allow_lds(attn_fwd_pipe_kernel<T>, 160 * 1024), true);
+      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024), true);
       (void)once2;
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
       const dim3 agrid(((N + 127) / 128) * nh * S);
-      if (piped && !tr)
-        hipLaunchKernelGGL((attn_fwd_pipe_kernel<T>), agrid, dim3(256), 5 * AttnK<T>::TILE + ldspad, st, a);
-      else if (tr)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
+      const int relh_lds = 4 * 32 * (hp | 1) * 4;  // per-wave relh tables (relh_stride)
+      if (tr)
+        hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds + ldspad, st, a);
       else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), 4 * AttnK<T>::TILE + ldspad, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds + ldspad, st, a);
       CHECK_LAUNCH();
     }
     {
@@ -385,10 +371,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   T* qt = c.template at<T>("qt");
   T* dot = c.template at<T>("dot");
   float* delta = c.template at<float>("delta");
-  float* drelh = c.template at<float>("drelh");
-  float* drelw = c.template at<float>("drelw");
-  float* relh = c.template at<float>("relh");
-  float* relw = c.template at<float>("relw");
   float* relhT = c.template at<float>("relhT");
   float* relwT = c.template at<float>("relwT");
 
@@ -464,7 +446,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     {  // attention backward on the B image streams
       {
         RelTabArgs r{};
-        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relh = relh; r.relw = relw; r.relhT = relhT; r.relwT = relwT;
+        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relhT = relhT; r.relwT = relwT;  // query-major tables: in-kernel (dQ)
         r.S = B; r.nh = nh; r.N = N; r.hp = hp; r.wp = wp; r.alpha = 1.0f / scale;
         hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, r);
         CHECK_LAUNCH();
@@ -481,30 +463,27 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         CHECK_LAUNCH();
       }
       AttnArgs a{};
-      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.relh = relh;
-      a.relw = relw; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv; a.drelh = drelh; a.drelw = drelw;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.rel_cat = m->lw(l, 18);
+      a.rel_catT = m->lw(l, 19); a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static bool once = (allow_lds(attn_bwd_dq_kernel<T, false>, 6 * AttnK<T>::TILE),
-                          allow_lds(attn_bwd_dq_kernel<T, can_tr>, 6 * AttnK<T>::TILE), true);
+      static const int qprio = getenv("BSG_ATTN_PRIO_DQ") ? atoi(getenv("BSG_ATTN_PRIO_DQ")) : 0;
+      a.prio = qprio;
+      static bool once = (allow_lds(attn_bwd_dq_kernel<T, false>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, can_tr>, 160 * 1024), true);
       (void)once;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
         const dim3 qgrid(((N + 127) / 128) * nh * B);
-        if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, can_tr>), qgrid, dim3(256), 4 * AttnK<T>::TILE, st, a);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false>), qgrid, dim3(256), 6 * AttnK<T>::TILE, st, a);
+        const int relh_lds = 4 * 32 * (hp | 1) * 4;
+        if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, can_tr>), qgrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds, st, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false>), qgrid, dim3(256), 6 * AttnK<T>::TILE + relh_lds, st, a);
       }
       CHECK_LAUNCH();
-      {
-        RelBwdArgs rb{};
-        rb.dq = dqkv; rb.ld = 3 * D; rb.rel_catT = m->lw(l, 19); rb.drelh = drelh; rb.drelw = drelw; rb.S = B; rb.nh = nh;
-        rb.N = N; rb.hp = hp; rb.wp = wp;
-        hipLaunchKernelGGL((relpos_bwd_mfma_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, rb);
-        CHECK_LAUNCH();
-      }
       AttnBwdKvArgs k{};
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
+      static const int kprio = getenv("BSG_ATTN_PRIO_DKV") ? atoi(getenv("BSG_ATTN_PRIO_DKV")) : 0;
+      k.prio = kprio;
       static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, false>, 2 * DkvK<T, false>::STAGE),
                            allow_lds(attn_bwd_dkv_kernel<T, can_tr>, 2 * DkvK<T, can_tr>::STAGE), true);
       (void)once2;
