@@ -150,25 +150,28 @@ DEVI int relh_stride(int hp) { return hp | 1; }  // odd: lane-per-row accesses a
 
 template <typename T>
 DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int wp, int qh, int qw,
-                             float alpha, float* scratch_w /* 32 x 64 floats */, float* table_h /* 32 x HS */,
-                             f32x16& rwv, int lane) {
+                             int qh_first, int qh_last /* wave-uniform range of qh */, float alpha,
+                             float* scratch_w /* 32 x 64 floats */, float* table_h /* 32 x HS */, f32x16& rwv, int lane) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   const int h = lane >> 5, col = lane & 31;
   const int HS = relh_stride(hp), nrelh = 2 * hp - 1, nrelw = 2 * wp - 1, LH = (2 * hp + 15) & ~15;
   const char* rc = (const char*)rel_cat + h * 16;  // chunk 2 ks + h of a 128-byte row
-  // Groups of up to four 32-row blocks of the table: all A chunks are fetched (L2) before the first MFMA, rows past
-  // the table are clamped and their results land in the spare slot `hp` of the row (no exec juggling per store).
-  for (int blk0 = 0; blk0 * 32 < nrelh; blk0 += 4) {
-    Chunk af[4][C::KS_D];
+  // h part: query row qh needs rel rows qh .. qh + hp - 1, so the wave's 32 queries need the window
+  // [qh_first, qh_last + hp - 1] only (two 32-row blocks for the 56 x 28 grid).  All A chunks of a group are fetched
+  // (L2) before the first MFMA; rows past the table are clamped and results outside a lane's own window land in the
+  // spare slot `hp` of its row (no exec juggling per store).
+  const int nrows = hp + qh_last - qh_first;
+  for (int blk0 = 0; blk0 * 32 < nrows; blk0 += 2) {
+    Chunk af[2][C::KS_D];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rr = min((blk0 + i) * 32 + col, nrelh - 1);
+    for (int i = 0; i < 2; ++i) {
+      const int rr = min(qh_first + (blk0 + i) * 32 + col, nrelh - 1);
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) af[i][ks] = *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + ks * 32);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -176,7 +179,7 @@ DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* re
       for (int ks = 0; ks < C::KS_D; ++ks) mma32(acc, af[i][ks], qf[ks]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kh = qh + hp - 1 - ((blk0 + i) * 32 + acc32_row(r, h));
+        const int kh = qh + hp - 1 - (qh_first + (blk0 + i) * 32 + acc32_row(r, h));
         table_h[col * HS + ((unsigned)kh < (unsigned)hp ? kh : hp)] = acc[r] * alpha;
       }
     }
@@ -216,8 +219,8 @@ DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* re
 // Backward of the above into dq: acc[blk][.] (d = 32 blk + ..., lane = query) = sum_rel rel_catT[d][rel] X[rel][q],
 // X[rel][q] = drel[q][pos + size - 1 - rel] gathered per lane from the per-wave LDS images of d relh / d relw.
 template <typename T>
-DEVI void relpos_wave_bwd(f32x16 (&acc)[2], const void* rel_catT, int hp, int wp, int qh, int qw, const float* table_h,
-                          const float* image_w /* 32 x 33 */, int lane) {
+DEVI void relpos_wave_bwd(f32x16 (&acc)[2], const void* rel_catT, int hp, int wp, int qh, int qw, int qh_first, int qh_last,
+                          const float* table_h, const float* image_w /* 32 x 33 */, int lane) {
   typedef typename Traits<T>::Chunk Chunk;
   constexpr int EPC = Traits<T>::EPC, KG = 4;  // k-steps whose A chunks are fetched together
   const int h = lane >> 5, col = lane & 31;
@@ -228,8 +231,10 @@ DEVI void relpos_wave_bwd(f32x16 (&acc)[2], const void* rel_catT, int hp, int wp
   for (int part = 0; part < 2; ++part) {
     const int len = part == 0 ? LH : LW, size = part == 0 ? hp : wp, pos = part == 0 ? qh : qw;
     const float* src = part == 0 ? table_h + col * HS : image_w + col * 33;
-    const int cbase = part == 0 ? 0 : LH, nks = len / (2 * EPC);
-    for (int ks0 = 0; ks0 < nks; ks0 += KG) {
+    // contraction k-steps: the h part only over the wave's window of rel rows [qh_first, qh_last + hp - 1]
+    const int cbase = part == 0 ? 0 : LH;
+    const int nks = part == 0 ? min((qh_last + hp - 1) / (2 * EPC) + 1, len / (2 * EPC)) : len / (2 * EPC);
+    for (int ks0 = part == 0 ? qh_first / (2 * EPC) : 0; ks0 < nks; ks0 += KG) {
       Chunk af[KG][2], bf[KG];
 #pragma unroll
       for (int i = 0; i < KG; ++i) {
@@ -283,8 +288,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   // rel-pos bias of this wave's 32 queries (tile area doubles as the shear scratch before the first DMA)
   f32x16 rwv;
   float* relh_q = (float*)(smem + 4 * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
-  relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, 1.0f / a.scale, (float*)(smem + wave * 8192),
-                        relh_q - col * relh_stride(a.hp), rwv, lane);
+  const bool active = q0 < a.N;  // wave-uniform: a wave past the last query only helps with the DMA and the barriers
+  if (active)
+    relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
+                          1.0f / a.scale, (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   float m = -INFINITY, l = 0.f;
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       rh_next = f32x2{relh_q[2 * t + 2], relh_q[2 * t + 3]};
       issue(t + 1, buf ^ 1);
     }
+    if (!active) continue;
     const char* kt_l = smem + buf * 2 * C::TILE;
     const char* vt_l = kt_l + C::TILE;
 
@@ -430,8 +438,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   for (int i = 0; i < 16; ++i) drw[i] = 0.f;
   const int qh = q / a.wp, qw = q % a.wp;
   float* relh_q = (float*)(smem + 2 * NTILE * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
-  relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, qh, qw, 1.0f / a.scale, (float*)(smem + wave * 8192),
-                        relh_q - col * relh_stride(a.hp), rwv, lane);
+  const bool active = q0 < a.N;  // wave-uniform: a wave past the last query only helps with the DMA and the barriers
+  if (active)
+    relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, qh, qw, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp, 1.0f / a.scale,
+                          (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   const float lse = a.lse2[sh * npad + qpad];
@@ -481,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       issue(t + 1, buf ^ 1);
     }
 #endif
+    if (!active) continue;
     const char* k_l = smem + buf * NTILE * C::TILE;
     const char* v_l = k_l + C::TILE;
     const char* kt_l = k_l + 2 * C::TILE;  // !TR only
@@ -540,13 +551,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   }
   // rel-pos gradient straight into dq: d relw goes to a [32][33] image in this wave's slice of the (now idle) tile area
   __syncthreads();
+  if (!active) return;
   float* image_w = (float*)(smem + wave * 8192);
 #pragma unroll
   for (int r = 0; r < 16; ++r) image_w[col * 33 + acc32_row(r, h)] = drw[r];
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
   f32x16 racc[2];
-  relpos_wave_bwd<T>(racc, a.rel_catT, a.hp, a.wp, qh, qw, relh_q - col * relh_stride(a.hp), image_w, lane);
+  relpos_wave_bwd<T>(racc, a.rel_catT, a.hp, a.wp, qh, qw, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
+                     relh_q - col * relh_stride(a.hp), image_w, lane);
   if (q0 + col < a.N) {
     T* orow = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
 #pragma unroll
