@@ -30,8 +30,8 @@ struct AttnArgs {
   const void* rel_catT;  // backward: T [64][LH + LW]
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
-  float* lse2;        // [S][nh][Hp*32] (row-padded)  log2-domain logsumexp of the logits
-  float* delta;       // backward: [S][nh][Hp*32]  rowsum(dO * O): WRITTEN by the dQ kernel (from `out` = O), read by dK/dV
+  float* lse2;        // [S][nh][Hp*32] (entries 0..N-1 used, the rest stay 0)  log2-domain logsumexp of the logits
+  float* delta;       // backward: [S][nh][Hp*32] (same indexing)  rowsum(dO * O): WRITTEN by the dQ kernel, read by dK/dV
   void* dq;  // backward outputs, T [S*N][ld] at the q/k/v column offsets of the dqkv buffer
   void* dk;
   void* dv;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       for (int i = 0; i < 4; ++i)
         *(typename Traits<T>::Vec4*)(orow + 32 * db + 8 * i + 4 * h) =
             pack4<T>(o[db][4 * i] * inv, o[db][4 * i + 1] * inv, o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
-    if (h == 0 && a.lse2) a.lse2[sh * npad + (q / a.wp) * 32 + (q % a.wp)] = m * c2 + log2f(l);
+    if (h == 0 && a.lse2) a.lse2[sh * npad + q] = m * c2 + log2f(l);
   }
 }
 
@@ -414,7 +414,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   attn_set_prio(a.prio, wave);
   const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
-  const int qpad = (q / a.wp) * 32 + (q % a.wp);
   const long sh = (long)s * a.nh + head;
   const int npad = a.hp * 32;
   const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                           (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
-  const float lse = a.lse2[sh * npad + qpad];
+  const float lse = a.lse2[sh * npad + q];
   // delta[q] = sum_d dO[q][d] O[q][d]: each half-wave lane holds half of the row; published for the dK/dV kernel
   float dl = 0.f;
   {
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int j = 0; j < Traits<T>::EPC; ++j) dl += to_f32(dof[ks][j]) * to_f32(oc[j]);
     }
     dl += __shfl_xor(dl, 32, 64);
-    if (h == 0 && q0 + col < a.N) a.delta[sh * npad + qpad] = dl;
+    if (h == 0 && q0 + col < a.N) a.delta[sh * npad + q] = dl;
   }
   f32x16 dqt[2];
 #pragma unroll
@@ -574,13 +573,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------- backward: dK, dV
 // Key-stationary: each wave owns one key tile (64 slots = 2 grid rows) and keeps dK^T, dV^T for it in
-// accumulators while the workgroup streams query tiles (2 grid rows of Q, dO, Q^T, dO^T) through LDS.
+// accumulators while the workgroup streams query tiles through LDS: 64 CONSECUTIVE tokens each (queries are the
+// register / contraction index here, so they need no row padding: ceil(N / 64) tiles instead of Hp / 2).
 // Here the KEY is on the lane (S = Q K^T un-swapped), so P and dS accumulators are the B operands of
 // dV^T += dO^T P and dK^T += Q^T dS.  Bias / lse2 / delta arrive in query-slot-major ("T") layouts:
-//   relwT [S][nh][32 kw][Hp*32],  relhT [S][nh][Hp key rows][Hp*32],  lse2/delta [S][nh][Hp*32].
+//   relwT [S][nh][32 kw][Hp*32],  relhT [S][nh][Hp key rows][Hp*32],  lse2/delta [S][nh][Hp*32], column = token;
+//   columns N .. 64 ceil(N/64) - 1 of relwT hold -inf (P = 0 there), of the others 0.
 struct AttnBwdKvArgs {
   const void* k; const void* v; const void* q; const void* dout;  // row-major T (q/k/v with ld, dout with ldo)
-  const void* qt; const void* dot;                                // [S][nh][64][Hp*32]
+  const void* qt; const void* dot;                                // [S][nh][64][Hp*32], column = token (f32 path)
   long ld, ldo;
   const float* relwT; const float* relhT; const float* lse2; const float* delta;
   void* dk; void* dv;  // T, row stride ld
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   int bx, head, s;
   attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
   attn_set_prio(a.prio, wave);
-  const int nt = a.hp >> 1;
+  const int nt = (a.N + 63) >> 6;
   const int kr0 = bx * 8;
   const bool wave_valid = kr0 + wave < a.hp;
   const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
@@ -656,10 +657,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   auto issue = [&](int t, int buf) {
     char* base = smem + buf * STAGE;
     dma_rows<RB, 64, 8, true>(base, wave, lane, [&](int r) {
-      return qbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
+      return qbase + (long)min(t * 64 + r, a.N - 1) * a.ld * sizeof(T);
     });
     dma_rows<RB, 64, 8, true>(base + C::TILE, wave, lane, [&](int r) {
-      return dobase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ldo * sizeof(T);
+      return dobase + (long)min(t * 64 + r, a.N - 1) * a.ldo * sizeof(T);
     });
     if constexpr (!TR) {
       dma_rows<RB, 64, 8, true>(base + 2 * C::TILE, wave, lane,
@@ -763,8 +764,8 @@ struct RelTabArgs {
   const void* rel_cat;  // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2hp).., zeros elsewhere
   float* relh;   // [S][nh][N][hp] or null (the attention kernels compute their own; kept for tests / f32 debugging)
   float* relw;   // [S][nh][N][32] or null
-  float* relhT;  // [S][nh][hp][hp*32] or null
-  float* relwT;  // [S][nh][32][hp*32] or null
+  float* relhT;  // [S][nh][hp][hp*32] or null; column = token
+  float* relwT;  // [S][nh][32][hp*32] or null; column = token, -inf for kw >= wp and in columns N .. 64 ceil(N/64) - 1
   int S, nh, N, hp, wp;
   float alpha;  // 1 / scale
 };
@@ -810,7 +811,8 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
         if (qvalid && a.relh) *(f32x4*)(a.relh + (sh * a.N + q) * a.hp + kh0) = v;
         if (a.relhT) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a.relhT[(sh * a.hp + kh0 + j) * npad + qh * 32 + col] = v[j];
+          for (int j = 0; j < 4; ++j)
+            if (qvalid) a.relhT[(sh * a.hp + kh0 + j) * npad + q] = v[j];
         }
       }
     }
@@ -840,9 +842,11 @@ __global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
     if (qs < a.wp)
       a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = col < a.wp ? g[qs * 65 + qs + a.wp - 1 - col] : -INFINITY;
   }
-  if (a.relwT) {  // relwT[kw][q slot]: lane = q slot
-    for (int kw = h; kw < 32; kw += 2)
-      a.relwT[(sh * 32 + kw) * npad + qh * 32 + col] =
-          (qvalid && kw < a.wp) ? g[col * 65 + col + a.wp - 1 - min(kw, a.wp - 1)] : -INFINITY;
+  if (a.relwT) {  // relwT[kw][token]: lane = query of this grid row; the last row's wave also fills the tail columns
+    for (int kw = h; kw < 32; kw += 2) {
+      if (qvalid) a.relwT[(sh * 32 + kw) * npad + q] = kw < a.wp ? g[col * 65 + col + a.wp - 1 - kw] : -INFINITY;
+      if (qh == a.hp - 1)
+        for (int c = a.N + col; c < ((a.N + 63) & ~63); c += 32) a.relwT[(sh * 32 + kw) * npad + c] = -INFINITY;
+    }
   }
 }

@@ -234,11 +234,13 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(T* __restrict__ dq, lon
 }
 
 // ------------------------------------------------------------------------------------- head transposes
-// X [S*N][ld] (head columns) -> XT [S][nh][64][Hp*32]; one block per (grid row, group of hb <= 4 heads, stream);
-// 16-byte loads of the contiguous hb*64-element row segments, 16-byte stores of 8 slots; padded slots = 0.
+// X [S*N][ld] (head columns) -> XT [S][nh][64][row_len]; one block per (group of 32 output columns, group of hb <= 4
+// heads, stream).  Group g holds tokens g * tpg + kw, kw < tpg: tpg = Wp gives the row-padded layout of the key-side
+// operands (group = grid row), tpg = 32 the dense token layout of the query-side operands of the dK/dV kernel.
+// 16-byte loads of the contiguous hb*64-element row segments, 16-byte stores of 8 columns; padded columns = 0.
 template <typename T>
 __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict__ x, long ld, T* __restrict__ xt,
-                                                              int N, int hp, int wp, int nh, int hb) {
+                                                              int N, int tpg, int row_len, int nh, int hb) {
   constexpr int EPC = Traits<T>::EPC;
   typedef typename Traits<T>::Chunk Chunk;
   __shared__ float tile[32][257];
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
   for (int i = tid; i < 32 * cpt; i += 256) {
     const int kw = i / cpt, c = i % cpt;
     float v[EPC];
-    if (kw < wp) {
-      const Chunk ch = *(const Chunk*)(x + ((long)s * N + gr * wp + kw) * ld + head0 * 64 + c * EPC);
+    if (kw < tpg && gr * tpg + kw < N) {
+      const Chunk ch = *(const Chunk*)(x + ((long)s * N + gr * tpg + kw) * ld + head0 * 64 + c * EPC);
 #pragma unroll
       for (int j = 0; j < EPC; ++j) v[j] = to_f32(ch[j]);
     } else {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
   __syncthreads();
   for (int i = tid; i < hb * 64 * 4; i += 256) {
     const int g = i & 3, hd = i >> 2;  // hd = head_local*64 + d; g = group of 8 output positions
-    T* dst = xt + (((long)s * nh + head0 + (hd >> 6)) * 64 + (hd & 63)) * (hp * 32) + gr * 32 + 8 * g;
+    T* dst = xt + (((long)s * nh + head0 + (hd >> 6)) * 64 + (hd & 63)) * row_len + gr * 32 + 8 * g;
     // bf16: every 16-slot group is stored permuted (position 8h + 4a + i holds slot 8a + 4h + i) so that the MFMA
     // operand matching an S^T accumulator is one aligned 16-byte chunk (attention.hpp, lds_perm_chunk)
     const int s0 = sizeof(T) == 2 ? 16 * (g >> 1) + 4 * (g & 1) : 8 * g;       // slots of positions 0..3

@@ -252,7 +252,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       if (!tr) {
         const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
         hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N,
-                           hp, wp, nh, hb);
+                           wp, hp * 32, nh, hb);
         CHECK_LAUNCH();
       }
       AttnArgs a{};
@@ -456,10 +456,11 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       const bool tr = can_tr && tr_env;
       if (!tr) {
         const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
-        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, hp, wp, nh, hb);
-        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, hp, wp, nh, hb);
-        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, hp, wp,
-                           nh, hb);
+        const int npad = hp * 32, dg = 2 * ((N + 63) / 64);  // key side: one group per grid row; query side: dense tokens
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, B), dim3(256), 0, st, qkv + D, (long)3 * D, kt, N, wp, npad, nh, hb);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(dg, nh / hb, B), dim3(256), 0, st, qkv, (long)3 * D, qt, N, 32, npad, nh, hb);
+        hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(dg, nh / hb, B), dim3(256), 0, st, (const T*)dn_b, (long)D, dot, N, 32,
+                           npad, nh, hb);
         CHECK_LAUNCH();
       }
       AttnArgs a{};
