@@ -28,6 +28,8 @@ struct AttnArgs {
   const void* dout;  // backward: dO, T [S*N][ldo]
   const void* rel_cat;   // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2 Hp)..
   const void* rel_catT;  // backward: T [64][LH + LW]
+  float* relhT;          // backward, WRITTEN by the dQ kernel for dK/dV: [S][nh][Hp][Hp*32], column = token
+  float* relwT;          // same: [S][nh][32][Hp*32]; -inf for kw >= Wp and in columns N .. 64 ceil(N/64) - 1
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
   float* lse2;        // [S][nh][Hp*32] (entries 0..N-1 used, the rest stay 0)  log2-domain logsumexp of the logits
@@ -87,6 +89,29 @@ DEVI void dma_tile(char* lds_tile, int wave, int lane, RowSrc row_src) {
     const char* src = row_src(r) + ((p ^ swz<RB>(r)) << 4);
     glds16(src, lds_tile + (wave * IPW + i) * 1024);
   }
+}
+
+// The same tile copy with the per-lane part of the source address hoisted out of the key loop: 32-bit byte offsets
+// (row offset at tile 0 + swizzled chunk) computed once, and a wave-uniform base that advances by a constant per tile,
+// so a tile costs one scalar add and the DMA instructions (SGPR base + VGPR offset) instead of re-deriving 64-bit
+// per-lane pointers.
+template <typename T> struct TileDma {
+  static constexpr int RB = 64 * sizeof(T), CPR = RB / 16, RPI = 64 / CPR, IPW = 64 / (4 * RPI);
+};
+template <typename T, typename RowOff>
+DEVI void dma_tile_offsets(unsigned (&off)[TileDma<T>::IPW], int wave, int lane, RowOff row_off) {
+  typedef TileDma<T> D;
+#pragma unroll
+  for (int i = 0; i < D::IPW; ++i) {
+    const int r = (wave * D::IPW + i) * D::RPI + lane / D::CPR, p = lane % D::CPR;
+    off[i] = (unsigned)row_off(r) + ((p ^ swz<D::RB>(r)) << 4);
+  }
+}
+template <typename T>
+DEVI void dma_tile_issue(char* lds_tile, int wave, const char* base, const unsigned (&off)[TileDma<T>::IPW]) {
+  typedef TileDma<T> D;
+#pragma unroll
+  for (int i = 0; i < D::IPW; ++i) glds16(base + off[i], lds_tile + (wave * D::IPW + i) * 1024);
 }
 
 template <typename T> DEVI typename Traits<T>::Chunk lds_chunk(const char* tile, int row, int chunk) {
@@ -300,18 +325,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
 
   const int nt = a.hp >> 1;
+  // tile t = grid rows 2t, 2t + 1: every source row advances by 2 Wp tokens per tile
+  unsigned koff[TileDma<T>::IPW], voff[TileDma<T>::IPW];
+  const long es = sizeof(T), kstep = 2L * a.wp * a.ld * es, vstep = TR ? kstep : 64 * es;
+  dma_tile_offsets<T>(koff, wave, lane, [&](int r) { return (long)slot_token(r >> 5, r & 31, a.wp) * a.ld * es; });
+  if constexpr (TR) {
+#pragma unroll
+    for (int i = 0; i < TileDma<T>::IPW; ++i) voff[i] = koff[i];
+  } else {
+    dma_tile_offsets<T>(voff, wave, lane, [&](int r) { return (long)r * npad * es; });
+  }
   auto issue = [&](int t, int buf) {
     char* kt_l = smem + buf * 2 * C::TILE;
-    char* vt_l = kt_l + C::TILE;
-    dma_tile<T>(kt_l, wave, lane, [&](int r) {
-      return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
-    });
-    if constexpr (TR)
-      dma_tile<T>(vt_l, wave, lane, [&](int r) {
-        return vtbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
-      });
-    else
-      dma_tile<T>(vt_l, wave, lane, [&](int r) { return vtbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_tile_issue<T>(kt_l, wave, kbase + t * kstep, koff);
+    dma_tile_issue<T>(kt_l + C::TILE, wave, vtbase + t * vstep, voff);
   };
 
   f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
@@ -441,6 +468,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   if (active)
     relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, qh, qw, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp, 1.0f / a.scale,
                           (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
+  // publish the key-major copies the dK/dV kernel streams (lane = key there): 128-byte row segments per half-wave
+  if (q0 + col < ((a.N + 63) & ~63)) {
+    const bool real = q0 + col < a.N;  // tail columns up to the dK/dV tile boundary: -inf bias, i.e. P = 0
+    float* wT = a.relwT + sh * 32 * npad + q0 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wT[(long)acc32_row(r, h) * npad] = real ? rwv[r] : -INFINITY;
+    if (real) {
+      float* hT = a.relhT + sh * a.hp * npad + q0 + col;
+      for (int kh = h; kh < a.hp; kh += 2) hT[(long)kh * npad] = relh_q[kh];
+    }
+  }
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   const float lse = a.lse2[sh * npad + q];
@@ -462,16 +500,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
 
   const int nt = a.hp >> 1;
+  unsigned koff[TileDma<T>::IPW], ktoff[TileDma<T>::IPW];
+  const long es = sizeof(T), kstep = 2L * a.wp * a.ld * es;
+  dma_tile_offsets<T>(koff, wave, lane, [&](int r) { return (long)slot_token(r >> 5, r & 31, a.wp) * a.ld * es; });
+  if constexpr (!TR) dma_tile_offsets<T>(ktoff, wave, lane, [&](int r) { return (long)r * npad * es; });
   auto issue = [&](int t, int buf) {
     char* k_l = smem + buf * NTILE * C::TILE;
-    dma_tile<T>(k_l, wave, lane, [&](int r) {
-      return kbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
-    });
-    dma_tile<T>(k_l + C::TILE, wave, lane, [&](int r) {
-      return vbase + (long)slot_token(2 * t + (r >> 5), r & 31, a.wp) * a.ld * sizeof(T);
-    });
-    if constexpr (!TR)
-      dma_tile<T>(k_l + 2 * C::TILE, wave, lane, [&](int r) { return ktbase + ((long)r * npad + t * 64) * sizeof(T); });
+    dma_tile_issue<T>(k_l, wave, kbase + t * kstep, koff);
+    dma_tile_issue<T>(k_l + C::TILE, wave, vbase + t * kstep, koff);
+    if constexpr (!TR) dma_tile_issue<T>(k_l + 2 * C::TILE, wave, ktbase + t * 64 * es, ktoff);
   };
 
   f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
@@ -748,105 +785,5 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
         *(typename Traits<T>::Vec4*)(dvrow + 32 * d + 8 * i + 4 * h) =
             pack4<T>(dvt[d][4 * i], dvt[d][4 * i + 1], dvt[d][4 * i + 2], dvt[d][4 * i + 3]);
       }
-  }
-}
-
-
-// --------------------------------------------------------------------------------- decomposed rel-pos tables
-// relh[q][kh] = q . rel_pos_h[qh - kh + Hp - 1] / scale,  relw[q][kw] = q . rel_pos_w[qw - kw + Wp - 1] / scale
-// (unscaled q, HF:268-311, HF:326-329) for one grid row of queries per wave, on MFMA, straight into the layouts
-// the attention kernels read.  S^T orientation (lane = query slot): for a fixed grid row the 56 needed rows of
-// rel_pos_h are ONE contiguous (reversed) window, so the h-part is a plain product; the w-part is Toeplitz in
-// (qw, kw), so G_w[q][rel] goes through a 32 x 65 LDS image and is read back sheared.
-struct RelTabArgs {
-  const void* q;  // T [S*N][ld], head h at columns h*64
-  long ld;
-  const void* rel_cat;  // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2hp).., zeros elsewhere
-  float* relh;   // [S][nh][N][hp] or null (the attention kernels compute their own; kept for tests / f32 debugging)
-  float* relw;   // [S][nh][N][32] or null
-  float* relhT;  // [S][nh][hp][hp*32] or null; column = token
-  float* relwT;  // [S][nh][32][hp*32] or null; column = token, -inf for kw >= wp and in columns N .. 64 ceil(N/64) - 1
-  int S, nh, N, hp, wp;
-  float alpha;  // 1 / scale
-};
-
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_tables_kernel(RelTabArgs a) {
-  typedef typename Traits<T>::Chunk Chunk;
-  typedef AttnK<T> C;
-  __shared__ float gw[4][32 * 65];
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.y, s = blockIdx.z;
-  const int qh = blockIdx.x * 4 + wave;
-  if (qh >= a.hp) return;  // whole wave; no block-level barrier below
-  const long sh = (long)s * a.nh + head;
-  const int npad = a.hp * 32, nrh = (2 * a.hp + 15) & ~15, nrw = 2 * a.wp - 1;  // rel_pos_w rows start at nrh
-  const bool qvalid = col < a.wp;
-  const long q = (long)qh * a.wp + (qvalid ? col : a.wp - 1);
-  Chunk qf[C::KS_D];
-  {
-    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
-#pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
-  }
-  const char* rc = (const char*)a.rel_cat;
-  // ---- h part: rows kh, window row = qh + hp-1 - kh
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    if (blk * 32 >= a.hp) break;
-    const int kh_l = blk * 32 + col;
-    const int rr = kh_l < a.hp ? qh + a.hp - 1 - kh_l : 0;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks)
-      mma32(acc, *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + (2 * ks + h) * 16), qf[ks]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kh0 = blk * 32 + 8 * i + 4 * h;
-      if (kh0 < a.hp) {
-        const f32x4 v = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]} * a.alpha;
-        if (qvalid && a.relh) *(f32x4*)(a.relh + (sh * a.N + q) * a.hp + kh0) = v;
-        if (a.relhT) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (qvalid) a.relhT[(sh * a.hp + kh0 + j) * npad + q] = v[j];
-        }
-      }
-    }
-  }
-  // ---- w part: G_w^T[rel][q] -> LDS image [q slot][rel] (stride 65) -> sheared reads
-  float* g = gw[wave];
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    if (blk * 32 >= nrw) break;
-    const int rel_l = blk * 32 + col;
-    const int rr = nrh + (rel_l < nrw ? rel_l : 0);
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks)
-      mma32(acc, *(const Chunk*)(rc + ((long)rr * 64) * sizeof(T) + (2 * ks + h) * 16), qf[ks]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g[col * 65 + blk * 32 + acc32_row(r, h)] = acc[r] * a.alpha;
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes are done (single-wave image)
-  __builtin_amdgcn_wave_barrier();
-  // relw[q][kw]: lane = kw, 16 queries per half-wave -> 128-byte coalesced rows
-  // padded key slots (kw >= wp) and padded query slots get -inf: the attention kernels need no masking
-  for (int j = 0; j < 16 && a.relw; ++j) {
-    const int qs = h * 16 + j;
-    if (qs < a.wp)
-      a.relw[(sh * a.N + (long)qh * a.wp + qs) * 32 + col] = col < a.wp ? g[qs * 65 + qs + a.wp - 1 - col] : -INFINITY;
-  }
-  if (a.relwT) {  // relwT[kw][token]: lane = query of this grid row; the last row's wave also fills the tail columns
-    for (int kw = h; kw < 32; kw += 2) {
-      if (qvalid) a.relwT[(sh * 32 + kw) * npad + q] = kw < a.wp ? g[col * 65 + col + a.wp - 1 - kw] : -INFINITY;
-      if (qh == a.hp - 1)
-        for (int c = a.N + col; c < ((a.N + 63) & ~63); c += 32) a.relwT[(sh * 32 + kw) * npad + c] = -INFINITY;
-    }
   }
 }

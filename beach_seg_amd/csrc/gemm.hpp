@@ -21,7 +21,6 @@ enum EpiMode {
   EPI_GELU_BWD = 6,   // out[m][n] = T(acc * aux[m][n]),  aux = gelu'(h) saved by EPI_BIAS_GELU
   EPI_UNPATCH = 7,    // patch-embed dgrad: scatter rows into the (B,3,H/2,W) fp32 prompt-pixel gradient
   EPI_NONE = 9,       // diagnostics: no stores (accumulators kept alive), to price the epilogue
-  EPI_RELPOS = 8,     // per head (blockIdx.y): q . [rel_pos_h; rel_pos_w]^T scattered into the relh / relw tables
 };
 
 struct GemmArgs {
@@ -44,12 +43,6 @@ struct GemmArgs {
   void* out2;
   const void* aux;  // T* (GELU_BWD pre-activation) or float* (resid / table)
   long ldaux;
-  // EPI_RELPOS: out = relh [S][nh][N][hp], out2 = relw [S][nh][N][32], out3/out4 = query-slot-major copies
-  // relhT [S][nh][hp][hp*32] / relwT [S][nh][32][hp*32] (may be null); blockIdx.y = head, A column offset head*64
-  void* out3;
-  void* out4;
-  int hp, nh;
-  float alpha;
   // A_FEAT / EPI_PLAIN row windows: GEMM row m <-> image m / a_rpg, token t_off + m % a_rpg (A_FEAT), and output
   // row (m / o_rpg) * o_gstride + o_off + m % o_rpg (EPI_PLAIN); o_rpg == 0 means the identity
   int t_off;
@@ -125,7 +118,7 @@ DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw,
 }
 
 template <typename T, int EPI>
-DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, int head) {
+DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
   if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
@@ -176,30 +169,6 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
         *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
             pack4<T>(v[0] * to_f32(h[0]), v[1] * to_f32(h[1]), v[2] * to_f32(h[2]), v[3] * to_f32(h[3]));
-      } else if (EPI == EPI_RELPOS) {
-        // column n of [rel_pos_h (2hp-1 rows); rel_pos_w (2wp-1 rows)]: rel index r <-> key kh = qh + hp-1 - r
-        // (HF:236-266 at q_size == k_size); only the entries that land inside the key grid are stored.
-        const int s = m / g.tokens, q = m % g.tokens, qh = q / g.wp, qw = q % g.wp;
-        const long sh = (long)s * g.nh + head;
-        const int npad = g.hp * 32, qpad = qh * 32 + qw, nh_rel = 2 * g.hp - 1, nw_rel = 2 * g.wp - 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int nn = n + r;
-          const float val = v[r] * g.alpha;
-          if (nn < nh_rel) {
-            const int kh = qh + g.hp - 1 - nn;
-            if (kh >= 0 && kh < g.hp) {
-              ((float*)g.out)[(sh * g.tokens + q) * g.hp + kh] = val;
-              if (g.out3) ((float*)g.out3)[(sh * g.hp + kh) * npad + qpad] = val;
-            }
-          } else if (nn < nh_rel + nw_rel) {
-            const int kw = qw + g.wp - 1 - (nn - nh_rel);
-            if (kw >= 0 && kw < g.wp) {
-              ((float*)g.out2)[(sh * g.tokens + q) * 32 + kw] = val;
-              if (g.out4) ((float*)g.out4)[(sh * 32 + kw) * npad + qpad] = val;
-            }
-          }
-        }
       } else if (EPI == EPI_UNPATCH) {
         // rows m = (b, t) over the TOP half tokens only (a_rpg = tokens/2); n = c*256 + i*16 + j
         const int half = g.tokens >> 1;
@@ -232,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   // activation tile is fetched from HBM once and the weight panel stays in the XCD's L2.
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm << 7, n0 = tn << 7;
-  const int head = blockIdx.y;  // EPI_RELPOS only (gridDim.y == 1 otherwise)
 
   // ---- per-lane source pointers (constant over K): 4 row groups of 8 rows per wave for A and for W
   const int prow = lane >> 3, pchunk = lane & 7;
@@ -252,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       const int ph = t / g.wp, pw = t % g.wp;
       base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
     }
-    if (EPI == EPI_RELPOS) base += head * 64;
     a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
     int n = n0 + r;
     if (n >= g.N) n = g.N - 1;
@@ -308,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     }
   }
 
-  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk, head);
+  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -330,7 +297,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
   const int bid = xcd_remap(blockIdx.x, nwg);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm << 8, n0 = tn << 7;
-  const int head = blockIdx.y;
 
   const int prow = lane >> 3, pchunk = lane & 7;
   const char* a_src[4];
@@ -349,7 +315,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
       const int ph = t / g.wp, pw = t % g.wp;
       base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
     }
-    if (EPI == EPI_RELPOS) base += head * 64;
     a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
   }
 #pragma unroll
@@ -413,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
         for (int mi = 0; mi < 4; ++mi) mma16(acc[ni][mi], fw[ks][ni], fa[ks][mi]);
     st = st == 2 ? 0 : st + 1;
   }
-  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk, head);
+  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -447,7 +412,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   const int gm = min(GM, tiles_m - grp * GM);
   const int tm = grp * GM + rem % gm, tn = rem / gm;
   const int m0 = tm << 8, n0 = tn << 8;
-  const int head = blockIdx.y;
   const int wm = wave >> 2, wn = wave & 3;
 
   // ---- DMA sources: quarter q, instruction j = 2*wave + i (i = 0, 1) covers 8 rows
@@ -479,7 +443,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
           const int ph = t / g.wp, pw = t % g.wp;
           base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
         }
-        if (EPI == EPI_RELPOS) base += head * 64;
         src[q][i] = (const char*)g.A + base * sizeof(T) + sc * 16;
       } else {
         int n = n0 + r;
@@ -572,22 +535,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     }
   }
   if (wm == 0) asm volatile("s_barrier" ::: "memory");  // balance the stagger
-  gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk, head);
-  gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk, head);
+  gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk);
+  gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk);
 }
 
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 3;
-  const dim3 gy(1, EPI == EPI_RELPOS ? g.nh : 1);
   if (ver == 1) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(256), 65536, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
   } else if (ver == 2 || g.N <= 192) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(512), 3 * 49152, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
   } else {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(tiles, gy.y), dim3(512), 131072, st, g);
+    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(tiles), dim3(512), 131072, st, g);
   }
 }

@@ -149,90 +149,6 @@ __global__ void patchify_kernel(const float* __restrict__ prompt_img, const floa
   }
 }
 
-// -------------------------------------------------------------------------------- decomposed rel-pos tables
-// relh[sh][q][kh] = q . rel_pos_h[qh - kh + Hp - 1] / scale,  relw[sh][q][kw] likewise (unscaled q, HF:326-329).
-// Also the query-slot-major copies used by the dK/dV kernel when `relhT` != nullptr.
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_fwd_kernel(const T* __restrict__ qkv, long ld,
-                                                          const float* __restrict__ rel_h,
-                                                          const float* __restrict__ rel_w, float* __restrict__ relh,
-                                                          float* __restrict__ relw, float* relhT, float* relwT, int N,
-                                                          int hp, int wp, int nh, float inv_scale) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* qs = (float*)smem;             // [64][65]
-  float* rh = qs + 64 * 65;             // [2hp-1][65]
-  float* rw = rh + (2 * hp - 1) * 65;   // [2wp-1][65]
-  const int head = blockIdx.y, s = blockIdx.z, q0 = blockIdx.x * 64, tid = threadIdx.x;
-  const long sh = (long)s * nh + head;
-  for (int i = tid; i < 64 * 64; i += 256) {
-    const int qi = i >> 6, c = i & 63, q = min(q0 + qi, N - 1);
-    qs[qi * 65 + c] = to_f32(qkv[((long)s * N + q) * ld + head * 64 + c]);
-  }
-  for (int i = tid; i < (2 * hp - 1) * 64; i += 256) rh[(i >> 6) * 65 + (i & 63)] = rel_h[i];
-  for (int i = tid; i < (2 * wp - 1) * 64; i += 256) rw[(i >> 6) * 65 + (i & 63)] = rel_w[i];
-  __syncthreads();
-  const int per = hp + wp, npad = hp * 32;
-  for (int i = tid; i < 64 * per; i += 256) {
-    const int qi = i / per, j = i % per, q = q0 + qi;
-    if (q >= N) continue;
-    const int qh = q / wp, qw = q % wp;
-    const float* r = j < hp ? rh + (qh - j + hp - 1) * 65 : rw + (qw - (j - hp) + wp - 1) * 65;
-    const float* qq = qs + qi * 65;
-    float acc = 0.f;
-#pragma unroll 16
-    for (int c = 0; c < 64; ++c) acc += qq[c] * r[c];
-    acc *= inv_scale;
-    const int qpad = qh * 32 + qw;
-    if (j < hp) {
-      relh[(sh * N + q) * hp + j] = acc;
-      if (relhT) relhT[(sh * hp + j) * npad + qpad] = acc;
-    } else {
-      relw[(sh * N + q) * 32 + (j - hp)] = acc;
-      if (relwT) relwT[(sh * 32 + (j - hp)) * npad + qpad] = acc;
-    }
-  }
-}
-
-// dq[q][c] += sum_kh drelh[q][kh] Rh[qh-kh+Hp-1][c] + sum_kw drelw[q][kw] Rw[qw-kw+Wp-1][c]
-template <typename T>
-__global__ __launch_bounds__(256) void relpos_bwd_kernel(T* __restrict__ dq, long ld, const float* __restrict__ rel_h,
-                                                          const float* __restrict__ rel_w,
-                                                          const float* __restrict__ drelh,
-                                                          const float* __restrict__ drelw, int N, int hp, int wp,
-                                                          int nh) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* rh = (float*)smem;            // [2hp-1][64]
-  float* rw = rh + (2 * hp - 1) * 64;  // [2wp-1][64]
-  const int head = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
-  const long sh = (long)s * nh + head;
-  for (int i = tid; i < (2 * hp - 1) * 64; i += 256) rh[i] = rel_h[i];
-  for (int i = tid; i < (2 * wp - 1) * 64; i += 256) rw[i] = rel_w[i];
-  __syncthreads();
-  const int q = blockIdx.x * 64 + (tid >> 2), c0 = (tid & 3) * 16;
-  if (q >= N) return;
-  const int qh = q / wp, qw = q % wp;
-  float acc[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-  const float* dh = drelh + (sh * N + q) * hp;
-  const float* dw = drelw + (sh * N + q) * 32;
-  for (int kh = 0; kh < hp; ++kh) {
-    const float g = dh[kh];
-    const float* r = rh + (qh - kh + hp - 1) * 64 + c0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] += g * r[c];
-  }
-  for (int kw = 0; kw < wp; ++kw) {
-    const float g = dw[kw];
-    const float* r = rw + (qw - kw + wp - 1) * 64 + c0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] += g * r[c];
-  }
-  T* p = dq + ((long)s * N + q) * ld + head * 64 + c0;
-#pragma unroll
-  for (int c = 0; c < 16; ++c) p[c] = from_f32<T>(to_f32(p[c]) + acc[c]);
-}
-
 // ------------------------------------------------------------------------------------- head transposes
 // X [S*N][ld] (head columns) -> XT [S][nh][64][row_len]; one block per (group of 32 output columns, group of hb <= 4
 // heads, stream).  Group g holds tokens g * tpg + kw, kw < tpg: tpg = Wp gives the row-padded layout of the key-side
@@ -272,24 +188,6 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const T* __restrict
     *(typename Traits<T>::Vec4*)(dst + 4) = pack4<T>(tile[s1][hd], tile[s1 + 1][hd], tile[s1 + 2][hd], tile[s1 + 3][hd]);
   }
 }
-
-// delta[sh][qpad] = sum_d dO[q][h*64+d] * O[q][h*64+d]; one wave per token row
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ dout, const T* __restrict__ o, long ld,
-                                                          float* __restrict__ delta, int S, int N, int hp, int wp,
-                                                          int nh) {
-  const long row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= (long)S * N) return;
-  const int s = row / N, q = row % N;
-  const int qpad = (q / wp) * 32 + q % wp;
-  for (int h = 0; h < nh; ++h) {
-    const float v = to_f32(dout[row * ld + h * 64 + lane]) * to_f32(o[row * ld + h * 64 + lane]);
-    const float t = wave_sum(v);
-    if (lane == 0) delta[((long)s * nh + h) * (hp * 32) + qpad] = t;
-  }
-}
-
 
 // feature_ensemble (HF:414-423): on the bottom (query) half of the canvas replace the attention-block output a[s]
 // by its mean over the streams of a group.  The proj GEMM has already written x_mid = x_in + a, so a is recovered

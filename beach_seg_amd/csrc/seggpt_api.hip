@@ -147,7 +147,7 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   g.stagger = stagger;
   static const int group_m = getenv("BSG_GEMM_GROUP_M") ? atoi(getenv("BSG_GEMM_GROUP_M")) : 0;
   g.group_m = group_m;
-  ProfScope ps(m, st, EPI == EPI_RELPOS ? (int)PC_ROW : (int)PC_GEMM, 2.0 * g.M * g.N * g.K);
+  ProfScope ps(m, st, PC_GEMM, 2.0 * g.M * g.N * g.K);
   // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
   // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
@@ -444,13 +444,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       CHECK_LAUNCH();
     }
     {  // attention backward on the B image streams
-      {
-        RelTabArgs r{};
-        r.q = qkv; r.ld = 3 * D; r.rel_cat = m->lw(l, 18); r.relhT = relhT; r.relwT = relwT;  // query-major tables: in-kernel (dQ)
-        r.S = B; r.nh = nh; r.N = N; r.hp = hp; r.wp = wp; r.alpha = 1.0f / scale;
-        hipLaunchKernelGGL((relpos_tables_kernel<T>), dim3((hp + 3) / 4, nh, B), dim3(256), 0, st, r);
-        CHECK_LAUNCH();
-      }
       static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
       constexpr bool can_tr = sizeof(T) == 2;  // bf16: K^T / Q^T / dO^T operands via transposing LDS reads of the row-major tiles
       const bool tr = can_tr && tr_env;
@@ -465,7 +458,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       }
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.rel_cat = m->lw(l, 18);
-      a.rel_catT = m->lw(l, 19); a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
+      a.rel_catT = m->lw(l, 19); a.relhT = relhT; a.relwT = relwT; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static const int qprio = getenv("BSG_ATTN_PRIO_DQ") ? atoi(getenv("BSG_ATTN_PRIO_DQ")) : 0;
       a.prio = qprio;
