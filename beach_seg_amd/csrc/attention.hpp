@@ -174,13 +174,12 @@ template <typename T> struct AttnK {
 DEVI int relh_stride(int hp) { return hp | 1; }  // odd: lane-per-row accesses are conflict-free
 
 template <typename T>
-DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int wp, int qh, int qw,
-                             int qh_first, int qh_last /* wave-uniform range of qh */, float alpha,
-                             float* scratch_w /* 32 x 64 floats */, float* table_h /* 32 x HS */, f32x16& rwv, int lane) {
+DEVI void relpos_wave_h(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int qh, int qh_first,
+                        int qh_last /* wave-uniform range of qh */, float alpha, float* table_h /* 32 x HS */, int lane) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   const int h = lane >> 5, col = lane & 31;
-  const int HS = relh_stride(hp), nrelh = 2 * hp - 1, nrelw = 2 * wp - 1, LH = (2 * hp + 15) & ~15;
+  const int HS = relh_stride(hp), nrelh = 2 * hp - 1;
   const char* rc = (const char*)rel_cat + h * 16;  // chunk 2 ks + h of a 128-byte row
   // h part: query row qh needs rel rows qh .. qh + hp - 1, so the wave's 32 queries need the window
   // [qh_first, qh_last + hp - 1] only (two 32-row blocks for the 56 x 28 grid).  All A chunks of a group are fetched
@@ -209,7 +208,19 @@ DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* re
       }
     }
   }
-  {  // w part: 2 wp - 1 <= 63 rows
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): single-wave image
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T>
+DEVI void relpos_wave_w(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int wp, int qw, float alpha,
+                        float* scratch_w /* 32 x 64 floats */, f32x16& rwv, int lane) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  const int h = lane >> 5, col = lane & 31;
+  const int nrelw = 2 * wp - 1, LH = (2 * hp + 15) & ~15;
+  const char* rc = (const char*)rel_cat + h * 16;
+  {  // 2 wp - 1 <= 63 rows
     Chunk af[2][C::KS_D];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -239,6 +250,14 @@ DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* re
     const float v = scratch_w[col * 64 + ((qw + wp - 1 - min(kw, wp - 1) + col) & 63)];
     rwv[r] = kw < wp ? v : -INFINITY;
   }
+}
+
+template <typename T>
+DEVI void relpos_wave_tables(const typename Traits<T>::Chunk* qf, const void* rel_cat, int hp, int wp, int qh, int qw,
+                             int qh_first, int qh_last, float alpha, float* scratch_w, float* table_h, f32x16& rwv,
+                             int lane) {
+  relpos_wave_h<T>(qf, rel_cat, hp, qh, qh_first, qh_last, alpha, table_h, lane);
+  relpos_wave_w<T>(qf, rel_cat, hp, wp, qw, alpha, scratch_w, rwv, lane);
 }
 
 // Backward of the above into dq: acc[blk][.] (d = 32 blk + ..., lane = query) = sum_rel rel_catT[d][rel] X[rel][q],
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE] | relh tables [4][32][HS]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
@@ -310,14 +329,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
   }
-  // rel-pos bias of this wave's 32 queries (tile area doubles as the shear scratch before the first DMA)
+  // rel-pos bias of this wave's 32 queries.  The tile area doubles as the shear scratch before the first DMA; the
+  // row part goes out to a key-major global scratch [kh][token] (coalesced both ways, L2-resident: written here,
+  // read back two floats per key tile) so that LDS holds only the K / V tiles and more workgroups fit per CU.
   f32x16 rwv;
-  float* relh_q = (float*)(smem + 4 * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
+  float* relh_g = a.relhT + sh * a.hp * npad + q0 + col;
   const bool active = q0 < a.N;  // wave-uniform: a wave past the last query only helps with the DMA and the barriers
-  if (active)
-    relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
-                          1.0f / a.scale, (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
+  if (active) {
+    float* slice = (float*)(smem + wave * max(8192, 128 * relh_stride(a.hp)));  // 32 x 64 shear image or 32 x HS relh table
+    relpos_wave_h<T>(qf, a.rel_cat, a.hp, q / a.wp, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp, 1.0f / a.scale, slice, lane);
+    if (q0 + col < a.N)
+      for (int kh = h; kh < a.hp; kh += 2) relh_g[(long)kh * npad] = slice[col * relh_stride(a.hp) + kh];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    relpos_wave_w<T>(qf, a.rel_cat, a.hp, a.wp, q % a.wp, 1.0f / a.scale, slice, rwv, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the scratch stores have left before this wave reads them back
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
+  if (q0 + col >= a.N) relh_g = a.relhT + sh * a.hp * npad + a.N - 1;  // clamped duplicate lanes read a valid column
   const float c2 = a.scale * 1.44269504088896340736f;
   float m = -INFINITY, l = 0.f;
   f32x16 o[2];
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     dma_tile_issue<T>(kt_l + C::TILE, wave, vtbase + t * vstep, voff);
   };
 
-  f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
+  f32x2 rh_next = f32x2{relh_g[0], relh_g[npad]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -349,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     wait_vm0();
     __syncthreads();
     if (t + 1 < nt) {
-      rh_next = f32x2{relh_q[2 * t + 2], relh_q[2 * t + 3]};
+      rh_next = f32x2{relh_g[(long)(2 * t + 2) * npad], relh_g[(long)(2 * t + 3) * npad]};
       issue(t + 1, buf ^ 1);
     }
     if (!active) continue;
@@ -407,6 +436,191 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           else mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
         }
       }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (q0 + col < a.N) {
+    const float inv = 1.f / l;
+    T* orow = (T*)a.out + ((long)s * a.N + q) * a.ldo + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *(typename Traits<T>::Vec4*)(orow + 32 * db + 8 * i + 4 * h) =
+            pack4<T>(o[db][4 * i] * inv, o[db][4 * i + 1] * inv, o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
+    if (h == 0 && a.lse2) a.lse2[sh * npad + q] = m * c2 + log2f(l);
+  }
+}
+
+// ---------------------------------------------------------------------------- forward, software-pipelined
+// The kernel above runs S^T MFMAs -> softmax VALU -> PV MFMAs strictly in turn inside a wave, and two waves per SIMD
+// do not hide that (measured: per key tile the wave spends about the SUM of its matrix time and its VALU issue time).
+// Here the dependent chain is cut across tiles and the two streams are interleaved BY HAND in one basic block:
+// eight slices per tile, each = operand reads, the exponentials of two accumulator rows of tile t, then one S^T MFMA
+// of tile t+1 and (second half) one PV MFMA of tile t, fenced by sched_barrier so the compiler keeps the order.  The
+// last PV k-step runs under the running-max update of tile t+1.  K tiles arrive two ahead (3-deep ring), V one ahead.
+template <typename T, bool TR>
+__global__ __launch_bounds__(256, 2) void attn_fwd_sp_kernel(AttnArgs a) {
+  typedef typename Traits<T>::Chunk Chunk;
+  typedef AttnK<T> C;
+  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  constexpr int NSL = 8;                       // slices per tile
+  constexpr int NSC = 2 * C::KS_D / NSL;       // S^T MFMA calls per slice (bf16 1, f32 2)
+  constexpr int WIN = NSL / C::KS_B;           // slices a PV k-step is spread over (bf16 4, f32 2)
+  constexpr int NPC = 4 / WIN;                 // PV MFMA calls per slice inside a window (bf16 1, f32 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [3][TILE] | V ring [2][TILE] | relh tables
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bx, head, s;
+  attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
+  const int q0 = bx * 128 + wave * 32;
+  const int q = min(q0 + col, a.N - 1);
+  const long sh = (long)s * a.nh + head;
+  const int npad = a.hp * 32;
+  const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
+  const char* vtbase = TR ? (const char*)a.v + ((long)s * a.N * a.ld + head * 64) * sizeof(T)
+                          : (const char*)a.vt + sh * 64 * npad * sizeof(T);
+  char* kring = smem;
+  char* vring = smem + 3 * C::TILE;
+
+  Chunk qf[C::KS_D];
+  {
+    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+  }
+  f32x16 rwv;
+  float* relh_q = (float*)(smem + 5 * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
+  const bool active = q0 < a.N;  // wave-uniform: a wave past the last query only helps with the DMA and the barriers
+  if (active)
+    relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
+                          1.0f / a.scale, (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
+  __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
+  const float c2 = a.scale * 1.44269504088896340736f;
+  float m = -INFINITY, l = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+
+  const int nt = a.hp >> 1;
+  unsigned koff[TileDma<T>::IPW], voff[TileDma<T>::IPW];
+  const long es = sizeof(T), kstep = 2L * a.wp * a.ld * es, vstep = TR ? kstep : 64 * es;
+  dma_tile_offsets<T>(koff, wave, lane, [&](int r) { return (long)slot_token(r >> 5, r & 31, a.wp) * a.ld * es; });
+  if constexpr (TR) {
+#pragma unroll
+    for (int i = 0; i < TileDma<T>::IPW; ++i) voff[i] = koff[i];
+  } else {
+    dma_tile_offsets<T>(voff, wave, lane, [&](int r) { return (long)r * npad * es; });
+  }
+  auto issue_k = [&](int t) { dma_tile_issue<T>(kring + (t % 3) * C::TILE, wave, kbase + t * kstep, koff); };
+  auto issue_v = [&](int t) { dma_tile_issue<T>(vring + (t & 1) * C::TILE, wave, vtbase + t * vstep, voff); };
+
+  // One tile step: softmax + PV of tile t from `sc`, S^T of tile t+1 into `sn` (for the last tile the ring slot is
+  // stale and `sn` is never used).
+  auto step = [&](int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
+    if (t > 0) {  // K(t+1) and V(t) were issued one step ago
+      wait_vm0();
+      __syncthreads();
+    }
+    if (t + 2 < nt) issue_k(t + 2);
+    if (t + 1 < nt) issue_v(t + 1);
+    if (!active) return;
+    const f32x2 rh = f32x2{relh_q[2 * t], relh_q[2 * t + 1]};
+    // running max (the last PV k-step of the previous tile is still in the matrix pipe under this)
+    float mx0 = sc[0][0], mx1 = sc[1][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, sc[0][r]); mx1 = fmaxf(mx1, sc[1][r]); }
+    float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    if (__builtin_amdgcn_ballot_w64(mn > m)) {  // wave-uniform: skip the O rescale once the running max is stable
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      m = mn;
+    }
+    const float nb0 = (rh[0] - m) * c2, nb1 = (rh[1] - m) * c2;
+    const char* kn_l = kring + ((t + 1) % 3) * C::TILE;
+    const char* v_l = vring + (t & 1) * C::TILE;
+    sn[0] = rwv;
+    sn[1] = rwv;
+    float ps = 0.f;
+    Chunk pb[2];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NSL; ++i) {
+      // (1) operands of the MFMAs at the end of this slice
+      Chunk ka[NSC], va[NPC];
+#pragma unroll
+      for (int c = 0; c < NSC; ++c) {
+        const int idx = i * NSC + c, b = idx & 1, ks = idx >> 1;
+        ka[c] = lds_chunk<T>(kn_l, 32 * b + col, 2 * ks + h);
+      }
+      const int pk = i / WIN - 1, pj = i % WIN;  // PV k-step whose window covers this slice (i >= WIN), position in it
+      if (i >= WIN) {
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+          const int cc = pj * NPC + c, b = cc >> 1, db = cc & 1;
+          if constexpr (TR) va[c] = lds_tr_chunk(v_l, db, b, pk, lane);
+          else va[c] = lds_perm_chunk(v_l, 32 * db + col, b, pk, h, T());
+        }
+      }
+      // (2) exponentials of accumulator rows 2i, 2i + 1 of both blocks
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * i + rr;
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[0][r], c2, nb0));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[1][r], c2, nb1));
+        sc[0][r] = p0;
+        sc[1][r] = p1;
+        ps += p0 + p1;
+      }
+      // (3) matrix work
+#pragma unroll
+      for (int c = 0; c < NSC; ++c) {
+        const int idx = i * NSC + c, b = idx & 1, ks = idx >> 1;
+        mma32(sn[b], ka[c], qf[ks]);
+      }
+      if (i >= WIN) {
+        if (pj == 0) { pb[0] = acc_chunk(sc[0], pk, T()); pb[1] = acc_chunk(sc[1], pk, T()); }
+#pragma unroll
+        for (int c = 0; c < NPC; ++c) {
+          const int cc = pj * NPC + c, b = cc >> 1, db = cc & 1;
+          mma32(o[db], va[c], pb[b]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l += ps;
+    // last PV k-step: overlaps the next step's max update (same wave) and the partner wave
+    pb[0] = acc_chunk(sc[0], C::KS_B - 1, T());
+    pb[1] = acc_chunk(sc[1], C::KS_B - 1, T());
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        if constexpr (TR) mma32(o[db], lds_tr_chunk(v_l, db, b, C::KS_B - 1, lane), pb[b]);
+        else mma32(o[db], lds_perm_chunk(v_l, 32 * db + col, b, C::KS_B - 1, h, T()), pb[b]);
+      }
+  };
+
+  f32x16 sa[2], sb[2];
+  issue_k(0);
+  issue_v(0);
+  if (nt > 1) issue_k(1);
+  wait_vm0();
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      sa[b] = rwv;
+#pragma unroll
+      for (int ks = 0; ks < C::KS_D; ++ks) mma32(sa[b], lds_chunk<T>(kring, 32 * b + col, 2 * ks + h), qf[ks]);
+    }
+  }
+  for (int t = 0; t < nt; t += 2) {
+    step(t, sa, sb);
+    if (t + 1 < nt) step(t + 1, sb, sa);
   }
   l += __shfl_xor(l, 32, 64);
   if (q0 + col < a.N) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/beach_seg_amd.h"
+#include <algorithm>
 #include "attention.hpp"
 #include "decoder.hpp"
 #include "gemm.hpp"
@@ -102,6 +103,7 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
   p.add("ln_out", -1, r2 * D * es);
   p.add("h_act", -1, r2 * mlp * es);
   p.add("vt", -1, 2 * (size_t)B * nh * 64 * npad * es);
+  p.add("relh_s", -1, 2 * (size_t)B * nh * hp * npad * 4);  // forward: key-major relh scratch [stream][head][kh][token]
   p.add("taps", -1, r1 * nt * D * es);
   p.add("feat", -1, (size_t)B * HW * 64 * es);
   if (train) {
@@ -209,6 +211,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   T* ln_out = c.template at<T>("ln_out");
   T* h_act = c.template at<T>("h_act");
   T* vt = c.template at<T>("vt");
+  float* relh_s = c.template at<float>("relh_s");
   T* taps = c.template at<T>("taps");
   T* feat = c.template at<T>("feat");
 
@@ -256,20 +259,23 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
         CHECK_LAUNCH();
       }
       AttnArgs a{};
-      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.out = attn_o;
+      a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.relhT = relh_s; a.out = attn_o;
       a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static const int fprio = getenv("BSG_ATTN_PRIO_FWD") ? atoi(getenv("BSG_ATTN_PRIO_FWD")) : 0;
       a.prio = fprio;
       static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
-      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024), true);
+      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024),
+                           allow_lds(attn_fwd_sp_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_sp_kernel<T, can_tr>, 160 * 1024), true);
       (void)once2;
+      static const bool sp = getenv("BSG_ATTN_FWD_SP") != nullptr;  // hand-interleaved variant: measured 7 % slower, kept for A/B
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
       const dim3 agrid(((N + 127) / 128) * nh * S);
       const int relh_lds = 4 * 32 * (hp | 1) * 4;  // per-wave relh tables (relh_stride)
-      if (tr)
-        hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds + ldspad, st, a);
-      else
-        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds + ldspad, st, a);
+      const int lds = (sp ? 5 * AttnK<T>::TILE + relh_lds : std::max(4 * AttnK<T>::TILE, relh_lds)) + ldspad;  // plain kernel: prologue scratch aliases the tiles
+      if (sp && tr) hipLaunchKernelGGL((attn_fwd_sp_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
+      else if (sp) hipLaunchKernelGGL((attn_fwd_sp_kernel<T, false>), agrid, dim3(256), lds, st, a);
+      else if (tr) hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
+      else hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), lds, st, a);
       CHECK_LAUNCH();
     }
     {
