@@ -33,7 +33,7 @@ struct AttnArgs {
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
   float* lse2;        // [S][nh][Hp*32] (entries 0..N-1 used, the rest stay 0)  log2-domain logsumexp of the logits
-  float* delta;       // backward: [S][nh][Hp*32] (same indexing)  rowsum(dO * O): WRITTEN by the dQ kernel, read by dK/dV
+  float* delta;       // backward: [S][nh][Hp*32] (same indexing)  MINUS rowsum(dO * O): WRITTEN by the dQ kernel, read by dK/dV
   void* dq;  // backward outputs, T [S*N][ld] at the q/k/v column offsets of the dqkv buffer
   void* dk;
   void* dv;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int j = 0; j < Traits<T>::EPC; ++j) dl += to_f32(dof[ks][j]) * to_f32(oc[j]);
     }
     dl += __shfl_xor(dl, 32, 64);
-    if (h == 0 && q0 + col < a.N) a.delta[sh * npad + q] = dl;
+    if (h == 0 && q0 + col < a.N) a.delta[sh * npad + q] = -dl;  // negated: the dK/dV kernel starts its dP accumulator from it
   }
   f32x16 dqt[2];
 #pragma unroll
@@ -834,7 +834,7 @@ struct AttnBwdKvArgs {
   const void* k; const void* v; const void* q; const void* dout;  // row-major T (q/k/v with ld, dout with ldo)
   const void* qt; const void* dot;                                // [S][nh][64][Hp*32], column = token (f32 path)
   long ld, ldo;
-  const float* relwT; const float* relhT; const float* lse2; const float* delta;
+  const float* relwT; const float* relhT; const float* lse2; const float* delta;  // delta holds MINUS rowsum(dO * O)
   void* dk; void* dv;  // T, row stride ld
   int S, nh, N, hp, wp;
   int prio;
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
         const f32x4 rh = *(const f32x4*)(st_l + (2 + wave) * 256 + c * 16);
         const f32x4 rw = *(const f32x4*)(rw_l + ((c ^ (col & 15)) << 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j] + rh[j]; dp[4 * i + j] = 0.f; }
+        for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j] + rh[j]; dp[4 * i + j] = dl4[i][j]; }  // dP accumulates onto -delta
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
         // padded key lanes / padded query slots carry relwT = -inf: P = 0 there without any masking
         const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse4[r >> 2][r & 3]));
         st[r] = p;                                   // P
-        dp[r] = p * (dp[r] - dl4[r >> 2][r & 3]);     // dS
+        dp[r] = p * dp[r];                           // dS = P (dP - delta)
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) {
