@@ -709,9 +709,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     dl += __shfl_xor(dl, 32, 64);
     if (h == 0 && q0 + col < a.N) a.delta[sh * npad + q] = -dl;  // negated: the dK/dV kernel starts its dP accumulator from it
   }
-  f32x16 dqt[2];
+  f32x16 dqt[2], ndl;  // ndl: loop-invariant initial accumulator of dP^T (all entries -delta[q])
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; ndl[i] = -dl; }
 
   const int nt = a.hp >> 1;
   unsigned koff[TileDma<T>::IPW], ktoff[TileDma<T>::IPW];
@@ -748,9 +748,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     float drh[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      f32x16 st = rwv, dp;  // S^T accumulator starts at relw (column bias)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      f32x16 st = rwv, dp = ndl;  // S^T accumulator starts at relw (column bias), dP^T at -delta
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
 #if BSG_DIAG_DQ == 3
@@ -774,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         sum = nb;
 #else
         const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, nb));  // 0 on padded key slots (bias -inf)
-        const float ds = p * (dp[r] - dl);
+        const float ds = p * dp[r];
         st[r] = ds;
         drw[r] += ds;
         sum += ds;
