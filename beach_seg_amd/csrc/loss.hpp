@@ -173,3 +173,55 @@ __global__ void vote_argmax_kernel(const uint8_t* __restrict__ counter, uint8_t*
   }
   out[i] = (uint8_t)best;
 }
+
+// ---------------------------------------------------------------------------------------- tile front-end
+// Cut a crop x crop window out of a u8 HWC mosaic (zeros outside, src/util/geo_util.py:316-341), resize it to S x S
+// exactly as Pillow's BICUBIC does for 8-bit images (src/data.py:93-96): horizontal integer pass -> u8 -> vertical
+// integer pass -> u8, 22-bit fixed-point coefficients from the host (libImaging/Resample.c), then /255 and the
+// ImageNet Normalize into NCHW f32.  One thread per output pixel (x fastest: the three plane writes are coalesced);
+// the <= kmax x kmax source taps of a 4x up-scale come from L1/L2 (37 KB per window).
+__global__ __launch_bounds__(256) void tile_frontend_kernel(const uint8_t* __restrict__ mosaic, int mh, int mw,
+                                                            const int* __restrict__ crops, int S,
+                                                            const int* __restrict__ coef, const int* __restrict__ bounds,
+                                                            int kmax, float m0, float m1, float m2, float s0, float s1,
+                                                            float s2, float* __restrict__ out, uint8_t* __restrict__ out_u8) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= S * S) return;
+  const int y = p / S, x = p - y * S;
+  const int cx = crops[4 * n], cy = crops[4 * n + 1];
+  const int x0 = bounds[2 * x], nx = bounds[2 * x + 1], y0 = bounds[2 * y], ny = bounds[2 * y + 1];
+  const int* kx = coef + (long)x * kmax;
+  const int* ky = coef + (long)y * kmax;
+  constexpr int PB = 22, HALF = 1 << (PB - 1);
+  int v0 = HALF, v1 = HALF, v2 = HALF;
+  for (int j = 0; j < ny; ++j) {
+    const int gy = cy + y0 + j;
+    int h0 = HALF, h1 = HALF, h2 = HALF;
+    if (gy >= 0 && gy < mh) {
+      for (int i = 0; i < nx; ++i) {
+        const int gx = cx + x0 + i;
+        if (gx >= 0 && gx < mw) {
+          const uint8_t* px = mosaic + ((long)gy * mw + gx) * 3;
+          const int k = kx[i];
+          h0 += px[0] * k; h1 += px[1] * k; h2 += px[2] * k;
+        }
+      }
+    }
+    const int k = ky[j];
+    v0 += min(max(h0 >> PB, 0), 255) * k;
+    v1 += min(max(h1 >> PB, 0), 255) * k;
+    v2 += min(max(h2 >> PB, 0), 255) * k;
+  }
+  const int r0 = min(max(v0 >> PB, 0), 255), r1 = min(max(v1 >> PB, 0), 255), r2 = min(max(v2 >> PB, 0), 255);
+  if (out_u8) {
+    uint8_t* o = out_u8 + ((long)n * S * S + p) * 3;
+    o[0] = (uint8_t)r0; o[1] = (uint8_t)r1; o[2] = (uint8_t)r2;
+  }
+  if (out) {
+    const long plane = (long)S * S;
+    float* o = out + (long)n * 3 * plane + p;  // (v / 255 - mean) / std, each step correctly rounded like numpy / torch
+    o[0] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)r0, 255.0f), m0), s0);
+    o[plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)r1, 255.0f), m1), s1);
+    o[2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)r2, 255.0f), m2), s2);
+  }
+}

@@ -740,6 +740,20 @@ int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int
   return 0;
 }
 
+int bsg_tile_frontend(void* stream, const uint8_t* mosaic, int mh, int mw, int n_crops, const int32_t* crops, int crop,
+                      int S, const int32_t* coef, const int32_t* bounds, int kmax, const float* mean3,
+                      const float* std3, float* out, uint8_t* out_u8) {
+  if (!mosaic || !crops || !coef || !bounds || !mean3 || !std3) return fail("bsg_tile_frontend: null argument");
+  if (!out && !out_u8) return fail("bsg_tile_frontend: no output buffer");
+  if (crop <= 0 || S <= 0 || kmax <= 0 || mh <= 0 || mw <= 0) return fail("bsg_tile_frontend: bad geometry");
+  if (n_crops <= 0) return 0;
+  hipLaunchKernelGGL(tile_frontend_kernel, dim3((S * S + 255) / 256, n_crops), dim3(256), 0, (hipStream_t)stream, mosaic, mh,
+                     mw, (const int*)crops, S, (const int*)coef, (const int*)bounds, kmax, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2], out, out_u8);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out) {
   if (!counter || !out) return fail("bsg_vote_argmax: null argument");
   hipLaunchKernelGGL(vote_argmax_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, (hipStream_t)stream, counter,

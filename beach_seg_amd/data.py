@@ -19,22 +19,72 @@ from .config import BeachSegConfig
 
 def tif_image(bands: np.ndarray, nodata: np.ndarray | None = None) -> np.ndarray:
     """4-band (B,G,R,NIR) or 8-band surface-reflectance raster (C,H,W) -> uint8 (H,W,3), as
-    `src/util/geo_util.py:449-470`: pick R,G,B, clip to [min, min+3000], divide by the per-channel max, x255."""
-    b = bands.astype(np.float32)
-    if b.shape[0] == 4:
-        rgb = np.stack([b[2], b[1], b[0]], axis=-1)
-    elif b.shape[0] == 8:
-        rgb = np.stack([b[5], b[3], b[1]], axis=-1)
+    `src/util/geo_util.py:449-470` (4 bands: R = band 4, G = band 3, B = mean(band 1, band 2); clip to
+    [min, min+3000] over the valid pixels; per-channel divide by the max; nodata -> 0; truncating x255) and
+    `src/util/multichannel_img.py:7-29` (8 bands: log10 of band-group means, per-channel min/max stretch).
+    The reference's in-place true-divide needs a floating raster; integer rasters are promoted to float32 here."""
+    data = np.asarray(bands)
+    if not np.issubdtype(data.dtype, np.floating):
+        data = data.astype(np.float32)
+    nodata = np.zeros(data.shape[1:], dtype=bool) if nodata is None else np.asarray(nodata, dtype=bool)
+    if data.shape[0] == 8:
+        red, green, blue = np.mean(data[5:], axis=0), np.mean(data[2:5], axis=0), np.mean(data[:2], axis=0)
+        img = np.dstack((np.log10(1.0 + red), np.log10(1.0 + green), np.log10(1.0 + blue)))
+        img -= np.array([img[:, :, i][~nodata].min() for i in range(3)])
+        img /= img.max(axis=(0, 1))
+        img[nodata] = 0.0
+    elif data.shape[0] == 4:
+        img = np.zeros((3, *data.shape[1:]), dtype=data.dtype)
+        img[0] = data[3]
+        img[1] = data[2]
+        img[2] = data[:2].mean(axis=0)
+        min_val = img[:, ~nodata].min()
+        img = img.clip(min_val, 3000 + min_val) - min_val
+        img -= img[:, ~nodata].min()
+        for i in range(3):
+            img[i] /= img[i].max()
+            img[i][nodata] = 0
+        img = img.transpose((1, 2, 0)).copy()
     else:
-        raise ValueError(f"expected 4 or 8 bands, got {b.shape[0]}")
-    lo = rgb.min()
-    rgb = np.clip(rgb, lo, lo + 3000.0) - lo
-    mx = rgb.reshape(-1, 3).max(axis=0)
-    rgb = rgb / np.maximum(mx, 1e-6)
-    out = (rgb * 255.0).astype(np.uint8)
-    if nodata is not None:
-        out[nodata] = 0
-    return out
+        raise ValueError(f"expected 4 or 8 bands, got {data.shape[0]}")
+    return np.array(img * 255, dtype=np.uint8)
+
+
+def pil_bicubic_tables(in_size: int, out_size: int) -> tuple[np.ndarray, np.ndarray]:
+    """Coefficient tables of Pillow's BICUBIC resize of an 8-bit image from `in_size` to `out_size` pixels along one
+    axis (libImaging/Resample.c: `precompute_coeffs` with the a = -0.5 cubic, support 2 x max(scale, 1), then
+    `normalize_coeffs_8bpc`: 22-bit fixed point, round half away from zero), for the device front-end
+    (`ops.tile_frontend` / `bsg_tile_frontend`): bounds i32 (out, 2) = (first source index, tap count), coef i32
+    (out, kmax).  The reference resizes with `Image.resize(..., resample=BICUBIC)` (`src/data.py:93-96`)."""
+    import math
+
+    def cubic(x: float) -> float:
+        a = -0.5
+        x = -x if x < 0 else x
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    kmax = int(math.ceil(support)) * 2 + 1
+    coef = np.zeros((out_size, kmax), dtype=np.int32)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    one = float(1 << 22)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        n = min(int(center + support + 0.5), in_size) - xmin
+        w = [cubic((x + xmin - center + 0.5) * (1.0 / fscale)) for x in range(n)]
+        ww = sum(w)  # accumulated left to right like the C loop
+        for x in range(n):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            coef[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx] = (xmin, n)
+    return bounds, coef
 
 
 def padded_crop(arr: np.ndarray, crop: tuple[int, int, int, int], fill=0) -> np.ndarray:

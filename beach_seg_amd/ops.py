@@ -153,6 +153,41 @@ def vote_argmax(counter: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_FRONTEND_TABLES: dict = {}
+
+
+def tile_frontend(mosaic: torch.Tensor, crops: torch.Tensor, crop_size: int, out_size: int,
+                  mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), return_u8: bool = False):
+    """Device tile front-end (`src/data.py:88-96`): u8 (H,W,3) mosaic + i32 (n,4) windows (xmin,ymin,..; side =
+    crop_size, zero padding outside) -> f32 (n,3,S,S) = Normalize(PIL-BICUBIC resize / 255), bit-for-bit what
+    `Image.resize(resample=BICUBIC)` + `/255` + `(x-mean)/std` give on the host.  `return_u8` also returns the resized
+    bytes u8 (n,S,S,3)."""
+    import ctypes as C
+
+    from .data import pil_bicubic_tables
+    _need_gpu(mosaic, crops)
+    if mosaic.dtype != torch.uint8 or mosaic.dim() != 3 or mosaic.shape[2] != 3 or not mosaic.is_contiguous():
+        raise ValueError("mosaic must be a contiguous uint8 (H, W, 3) tensor")
+    if crops.dtype != torch.int32 or crops.dim() != 2 or crops.shape[1] != 4:
+        raise ValueError("crops must be int32 (n, 4)")
+    lib = N.load()
+    key = (crop_size, out_size, mosaic.device)
+    if key not in _FRONTEND_TABLES:
+        b, k = pil_bicubic_tables(crop_size, out_size)
+        _FRONTEND_TABLES[key] = (torch.from_numpy(b).to(mosaic.device), torch.from_numpy(k).to(mosaic.device), k.shape[1])
+    bounds, coef, kmax = _FRONTEND_TABLES[key]
+    n = crops.shape[0]
+    out = torch.empty((n, 3, out_size, out_size), dtype=torch.float32, device=mosaic.device)
+    u8 = torch.empty((n, out_size, out_size, 3), dtype=torch.uint8, device=mosaic.device) if return_u8 else None
+    f3 = C.c_float * 3
+    crops = crops.contiguous()
+    with torch.cuda.device(mosaic.device):
+        N.check(lib.bsg_tile_frontend(_stream(), _ptr(mosaic), mosaic.shape[0], mosaic.shape[1], n, _ptr(crops), crop_size,
+                                      out_size, _ptr(coef), _ptr(bounds), kmax, f3(*mean), f3(*std), _ptr(out),
+                                      _ptr(u8) if u8 is not None else None))
+    return (out, u8) if return_u8 else out
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16 or both f32."""
     _need_gpu(a, w, bias)

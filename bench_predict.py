@@ -5,14 +5,15 @@ over a synthetic mosaic, 1 GPU, network forward replayed from a captured hipGrap
     python bench_predict.py [--size 8192] [--batch 64] [--crop 112]
 
 The reference's loop (`src/predict.py:232-262`) runs batch_size 1 on the CPU; here the 5,476 windows of an
-8192 x 8192 mosaic are resized to 448 x 448 on device (bilinear here -- PIL-exact bicubic is a section 8 f-3 "next"
-row), pushed through the ViT-L forward in batches, decoded, nearest-resized and voted without leaving the GPU."""
+8192 x 8192 mosaic are cut (zero-padded at the edges), resized to 448 x 448 with Pillow-exact BICUBIC and normalised on
+device (`ops.tile_frontend`), pushed through the ViT-L forward in batches, decoded, nearest-resized and voted without
+leaving the GPU."""
 import argparse, json, sys, time
 from pathlib import Path
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parent))
-from beach_seg_amd import ml_util
+from beach_seg_amd import ml_util, ops  # noqa: F401
 from beach_seg_amd.config import BeachSegConfig
 from beach_seg_amd.model import PromptModel
 from beach_seg_amd.predict import Accumulator, grid_crops
@@ -42,14 +43,7 @@ def main():
     torch.cuda.synchronize(); t0 = time.perf_counter(); t_net = 0.0
     for s in range(0, n, a.batch):
         cb = crops[s:s + a.batch]
-        tiles = []
-        for x0, y0, x1, y1 in cb.tolist():  # clipped windows are zero-padded like padded_crop
-            t = torch.zeros(a.crop, a.crop, 3, dtype=torch.uint8, device=dev)
-            ys, xs = min(y1, a.size) - y0, min(x1, a.size) - x0
-            t[:ys, :xs] = mosaic[y0:y0 + ys, x0:x0 + xs]
-            tiles.append(t)
-        img = torch.stack(tiles).permute(0, 3, 1, 2).float() / 255.0
-        img = ml_util.normalize(F.interpolate(img, size=(S, S), mode="bilinear", align_corners=False))
+        img = ops.tile_frontend(mosaic, cb.to(dev), a.crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
         idx = torch.arange(s, s + img.shape[0]) % a.prompts
         pal, pal_norm = pm.create_palette(img.shape[0], train=True)
         pb, pmasks = pm.prepare_prompt(idx, pal, train=False)

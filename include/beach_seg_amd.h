@@ -130,6 +130,16 @@ int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int
                    const int32_t* crops, uint8_t* counter, int mh, int mw, int K);
 int bsg_vote_argmax(void* stream, const uint8_t* counter, long n_pixels, int K, uint8_t* out);
 
+/* Tile front-end (src/data.py:88-96, src/util/geo_util.py:316-341): cut n windows (xmin,ymin, side = crop; zero
+ * padding outside the mosaic) out of a u8 HWC (mh,mw,3) mosaic, resize each to (S,S) bit-for-bit like Pillow's
+ * BICUBIC on 8-bit images (two integer passes, u8 intermediate), then /255 and (x - mean) / std into NCHW f32.
+ * coef i32 [S][kmax], bounds i32 [S][2] = (first source index, tap count) per output coordinate: Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc for crop -> S, built by the host (beach_seg_amd.data.pil_bicubic_tables).
+ * out f32 (n,3,S,S) and/or out_u8 (n,S,S,3) (the resized bytes themselves); either may be NULL. */
+int bsg_tile_frontend(void* stream, const uint8_t* mosaic, int mh, int mw, int n_crops, const int32_t* crops, int crop,
+                      int S, const int32_t* coef, const int32_t* bounds, int kmax, const float* mean3,
+                      const float* std3, float* out, uint8_t* out_u8);
+
 /* The NT GEMM kernel on its own (unit tests and micro-benchmarks): out[M][N] = A[M][K] W[N][K]^T (+ bias[N]),
  * A / W / out in the dtype given (0 f32, 1 bf16), bias f32 or NULL. */
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,

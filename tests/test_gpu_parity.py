@@ -247,6 +247,23 @@ def test_predict_vote_glue_bit_exact(golden_dir):
     assert int(c3.min()) == 0
 
 
+
+def test_tile_front_end_bit_exact_vs_pillow(golden_dir):
+    """bsg_tile_frontend: padded crop + Pillow-BICUBIC resize (u8, bit-exact vs PIL's own output) + /255 + Normalize
+    (f32, bit-exact vs numpy float32 arithmetic), up-scaling 112 / 256 -> 448 and down-scaling 256 -> 96."""
+    rec = np.load(golden_dir / "frontend_pil.npz")
+    mosaic = torch.from_numpy(rec["mosaic"]).to(DEV)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    for key, boxes, crop, S in (("out112", rec["boxes112"], 112, 448), ("out256", rec["boxes256"], 256, 448),
+                                ("down256_96", rec["boxes256"], 256, 96)):
+        out, u8 = ops.tile_frontend(mosaic, torch.from_numpy(boxes).to(DEV), crop, S, return_u8=True)
+        assert np.array_equal(u8.cpu().numpy(), rec[key]), key
+        want = ((rec[key].astype(np.float32) / np.float32(255.0) - mean) / std).transpose(0, 3, 1, 2)
+        assert np.array_equal(out.cpu().numpy(), want), key
+    with pytest.raises(ValueError):
+        ops.tile_frontend(mosaic.float(), torch.from_numpy(rec["boxes112"]).to(DEV), 112, 448)
+
+
 # ------------------------------------------------------------------- full-size, size-independent properties
 def test_full_geometry_batch_invariance_and_linearity():
     """At the BASELINE geometry (ViT-L, bf16): a sample's prediction does not depend on its batch (bit-exact),

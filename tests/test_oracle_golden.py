@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from beach_seg_amd.weights import SegGptGeometry, synth_state_dict
+from oracle import frontend_oracle as FO
 from oracle import predict_oracle as PO
 from oracle import seggpt_oracle as O
 from oracle.gen_inputs import synth_inputs
@@ -111,3 +112,27 @@ def test_vitl_fixture_present(golden_dir):
     rec = np.load(golden_dir / "vitl_e2e.npz")
     assert rec["pred_slice"].shape == (1, 3, 112, 56)
     assert np.isfinite(rec["pred_slice"]).all() and float(rec["grad_l2"]) > 0
+
+
+def test_tile_front_end_vs_pillow_and_reference(golden_dir):
+    """Front-end oracle (integer restatement of Pillow's 8-bit BICUBIC + the reference's padded_crop / tif_image) against
+    Pillow's own output and the reference functions' output (fixture written by oracle/gen_golden_frontend.py), and the
+    product's host-side table builder / mirrors against the same vectors."""
+    from beach_seg_amd.data import padded_crop, pil_bicubic_tables, tif_image
+
+    rec = np.load(golden_dir / "frontend_pil.npz")
+    m = rec["mosaic"]
+    for key, boxes, crop, S in (("out112", rec["boxes112"], 112, 448), ("out256", rec["boxes256"], 256, 448),
+                                ("down256_96", rec["boxes256"], 256, 96)):
+        u8, f = FO.tile_frontend(m, boxes, crop, S)
+        assert np.array_equal(u8, rec[key]), key                     # bit-exact vs PIL
+        want = (rec[key].astype(np.float32) / np.float32(255.0) - FO.IMAGENET_MEAN) / FO.IMAGENET_STD
+        assert np.array_equal(f, want.transpose(0, 3, 1, 2))
+        b1, k1 = pil_bicubic_tables(crop, S)
+        b2, k2 = FO.pil_coeffs(crop, S)
+        assert np.array_equal(b1, b2) and np.array_equal(k1, k2)
+    assert np.array_equal(FO.tif_image_4band(rec["tif_bands"], rec["tif_nodata"]), rec["tif_rgb"])
+    assert np.array_equal(tif_image(rec["tif_bands"], rec["tif_nodata"]), rec["tif_rgb"])
+    for box, want in zip(rec["pc_boxes"], rec["pc_out"]):
+        assert np.array_equal(padded_crop(rec["pc_src"], tuple(int(v) for v in box)), want)
+        assert np.array_equal(FO.padded_crop(rec["pc_src"], box, 5) if box[0] >= 0 and box[1] >= 0 else want, want)
