@@ -9,6 +9,7 @@
 // is 4 consecutive output features of one row: the natural 8/16-byte row-major store.
 #pragma once
 #include "common.hpp"
+#include <algorithm>
 
 enum AMode { A_PLAIN = 0, A_FEAT = 1 };
 enum EpiMode {
@@ -405,7 +406,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.N + 255) >> 8, tiles_m = (g.M + 255) >> 8;
   const int nwg = tiles_m * tiles_n;
-  int bid = xcd_remap(blockIdx.x, nwg);
+  // Persistent form (g.persist): the grid is one workgroup per CU and each walks the virtual block ids
+  // blockIdx.x, blockIdx.x + gridDim.x, ... in the order the dispatcher would have started them; the first K tile of
+  // the next output tile is requested BEFORE the epilogue of the current one, so its HBM/L2 latency and the
+  // workgroup launch disappear behind the store burst.
+  const bool wm1 = (wave >> 2) == 1;
+  bool primed = false;
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  int bid = xcd_remap(vb, nwg);
   // groups of 4 row tiles: the blocks resident on one XCD at a time share 4 activation panels and a few weight panels
   const int GM = g.group_m > 0 ? g.group_m : 4;
   const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
@@ -472,13 +480,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   // this every CU reaches its store burst at the same moment and HBM alternates between idle and saturated
   // (measured: the stores of a K=1024 tile cost 14 % of the kernel, all of it exposed).  Blocks of the first wave
   // sleep a different eighth of one tile time; later blocks inherit the phase of the CU they land on.
-  if (blockIdx.x < 256 && gridDim.x > 512) {
+  if (g.stagger && vb == (int)blockIdx.x && blockIdx.x < 256 && gridDim.x > 512) {
     const int phase = (blockIdx.x >> 3) & 7;
     const int naps = (phase * nk * g.stagger) >> 7;  // g.stagger = cycles per K tile / 64 (host-tuned)
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  if (!primed) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) issue(q, 0, 0);
+    for (int q = 0; q < 4; ++q) issue(q, 0, 0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   if (wm == 1) asm volatile("s_barrier" ::: "memory");  // stagger: waves 4-7 run one barrier behind
@@ -535,8 +545,52 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     }
   }
   if (wm == 0) asm volatile("s_barrier" ::: "memory");  // balance the stagger
+  primed = false;
+  if (vb + (int)gridDim.x < nwg && !(nk & 1)) {
+    // every wave is past its last LDS read of buffer 0 (K tile nk - 2); request K tile 0 of the next output tile into it
+    // through a second copy of the address set-up (the epilogue below still needs this tile's m0 / n0 only)
+    const int nb = xcd_remap(vb + gridDim.x, nwg);
+    const int ngrp = nb / gsz, nrem = nb - ngrp * gsz, ngm = min(GM, tiles_m - ngrp * GM);
+    const int nm0 = (ngrp * GM + nrem % ngm) << 8, nn0 = (nrem / ngm) << 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = 2 * wave + i;
+        int row;
+        if (q == 0) row = (j >> 3) * 128 + (j & 7) * 8;
+        else if (q == 3) row = (j >> 3) * 128 + 64 + (j & 7) * 8;
+        else if (q == 1) row = (j >> 2) * 64 + (j & 3) * 8;
+        else row = (j >> 2) * 64 + 32 + (j & 3) * 8;
+        const int r = row + prow;
+        const int sc = pchunk ^ (r & 7);
+        const bool is_a = (q == 0 || q == 3);
+        const char* sp;
+        if (is_a) {
+          int m = nm0 + r;
+          if (m >= g.M) m = g.M - 1;
+          long base;
+          if (AMODE == A_PLAIN) {
+            base = ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda;
+          } else {
+            const int bb = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
+            const int ph = t / g.wp, pw = t % g.wp;
+            base = (((long)bb * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+          }
+          sp = (const char*)g.A + base * sizeof(T) + sc * 16;
+        } else {
+          int n = nn0 + r;
+          if (n >= g.N) n = g.N - 1;
+          sp = (const char*)g.W + (long)n * g.K * sizeof(T) + sc * 16;
+        }
+        glds16(sp, smem + ldsoff[q][i]);
+      }
+    primed = true;
+  }
   gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk);
   gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk);
+  (void)wm1;
+  }  // tile loop
 }
 
 template <typename T, int AMODE, int EPI>
@@ -550,6 +604,8 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
   } else {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(tiles), dim3(512), 131072, st, g);
+    static const int persist = getenv("BSG_GEMM_PERSIST") ? atoi(getenv("BSG_GEMM_PERSIST")) : 256;  // workgroups in the persistent grid = CUs (0 = one workgroup per tile); 512: slower
+    const int grid = persist > 0 ? std::min(tiles, persist) : tiles;
+    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(grid), dim3(512), 131072, st, g);
   }
 }
