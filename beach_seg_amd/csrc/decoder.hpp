@@ -18,23 +18,26 @@ struct ConvArgs {
   float* pred;                           // fp32 NCHW [B][3][H][W]
   int H, W;
   float eps;
-  int ty0;  // first 8-row output tile (dgrad over a row window)
+  int ty0;  // first 16-row output tile (dgrad over a row window)
 };
 
-// Workgroup = 8 x 32 output pixels; wave w owns rows 2w, 2w+1 (64 pixels) x 64 output channels (4x4 MFMA 16x16).
+// Workgroup = 16 x 32 output pixels; wave w owns rows 4w .. 4w+3 (128 pixels) x 64 output channels (4 x 8 MFMA 16x16
+// tiles): every weight fragment fetched (L1/L2: the 73 KB filter bank is re-read by every wave) feeds 8 MFMAs.
+constexpr int CONV_TR = 16, CONV_RW = 4, CONV_HALO = (CONV_TR + 2) * 34;  // tile rows, rows per wave, halo pixels
 template <typename T, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   constexpr int EPC = Traits<T>::EPC, CPP = 64 / EPC;  // chunks per pixel: 8 (bf16) / 16 (f32)
   constexpr int PB = 64 * sizeof(T);                   // bytes per pixel
   constexpr int KS = CPP / 4;                          // 16x16 k-steps per tap
-  extern __shared__ __attribute__((aligned(16))) char halo[];  // [10][34] pixels x PB, chunk-swizzled
+  constexpr int NM = 2 * CONV_RW;                      // pixel tiles per wave: (row, x half)
+  extern __shared__ __attribute__((aligned(16))) char halo[];  // [TR + 2][34] pixels x PB, chunk-swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x0 = blockIdx.x * 32, y0 = (blockIdx.y + a.ty0) * 8, b = blockIdx.z;
+  const int x0 = blockIdx.x * 32, y0 = (blockIdx.y + a.ty0) * CONV_TR, b = blockIdx.z;
   const char* img = (const char*)a.in + (long)b * a.H * a.W * PB;
 
-  for (int i = tid; i < 340 * CPP; i += 256) {
+  for (int i = tid; i < CONV_HALO * CPP; i += 256) {
     const int pix = i / CPP, ch = i % CPP;
     const int hy = pix / 34, hx = pix % 34, y = y0 + hy - 1, x = x0 + hx - 1;
     Chunk v;
@@ -46,36 +49,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   __syncthreads();
 
   const int frow = lane & 15, fchunk = lane >> 4;
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[4][NM];  // [ni][mi]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
+#pragma unroll 1  // rolled: with 128 accumulator registers a fully unrolled tap loop hoists operand loads into spills
   for (int tap = 0; tap < 9; ++tap) {
-    const int dy = tap / 3, dx = tap % 3;
+    const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int c = fchunk + 4 * ks;
-      Chunk fa[4], fw[4];
+      Chunk fa[NM], fw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int pix = (2 * wave + (i >> 1) + dy) * 34 + (i & 1) * 16 + frow + dx;
-        fa[i] = *(const Chunk*)(halo + pix * PB + ((c ^ (pix & (CPP - 1))) << 4));
+      for (int i = 0; i < 4; ++i)
         fw[i] = *(const Chunk*)((const char*)a.w + (((long)(i * 16 + frow) * 9 + tap) * 64) * sizeof(T) + c * 16);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        const int pix = (CONV_RW * wave + (i >> 1) + dy) * 34 + (i & 1) * 16 + frow + dx;
+        fa[i] = *(const Chunk*)(halo + pix * PB + ((c ^ (pix & (CPP - 1))) << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
+        for (int mi = 0; mi < NM; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
     }
   }
 
-  // acc[ni][mi][r]: pixel (y0 + 2*wave + (mi>>1), x0 + (mi&1)*16 + frow), channel ni*16 + 4*fchunk + r
+  // acc[ni][mi][r]: pixel (y0 + 4*wave + (mi>>1), x0 + (mi&1)*16 + frow), channel ni*16 + 4*fchunk + r
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int y = y0 + 2 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + frow;
+  for (int mi = 0; mi < NM; ++mi) {
+    const int y = y0 + CONV_RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + frow;
     const long pix = ((long)b * a.H + y) * a.W + x;
     if (MODE == CONV_PLAIN) {
 #pragma unroll

@@ -345,11 +345,11 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     a.in = feat; a.w = m->gw(9); a.bias = (const float*)m->gw(11); a.out = train ? c.template at<T>("conv_out") : nullptr;
     a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
     a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
-    const int lds = 340 * 64 * sizeof(T);
-    static bool once = (allow_lds(conv3x3_kernel<T, CONV_FWD_FUSED>, 340 * 64 * sizeof(T)), true);
+    const int lds = CONV_HALO * 64 * sizeof(T);
+    static bool once = (allow_lds(conv3x3_kernel<T, CONV_FWD_FUSED>, CONV_HALO * 64 * sizeof(T)), true);
     (void)once;
     ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * 64 * 64);
-    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_FWD_FUSED>), dim3(a.W / 32, a.H / 8, B), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_FWD_FUSED>), dim3(a.W / 32, a.H / CONV_TR, B), dim3(256), lds, st, a);
     CHECK_LAUNCH();
   }
   return 0;
@@ -384,7 +384,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     // grad_pred is zero on canvas rows < first_row (the reference loss only covers the bottom half, src/model.py:53-57):
     // the 3x3 dgrad reaches one row above, so only token rows >= ph0 can carry a gradient into the encoder.
     const int ph0 = first_row > 0 ? (first_row - 1) / 16 : 0;
-    const int hb0 = std::max(0, 16 * ph0 - 8), ty0 = 2 * ph0, ntok = (hp - ph0) * wp;
+    const int hb0 = std::max(0, 16 * ph0 - 8), ty0 = ph0, ntok = (hp - ph0) * wp;  // ty0: first 16-row conv tile = first token row
     const long total = (long)B * (H - hb0) * W;
     hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
                        c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
@@ -392,12 +392,12 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     CHECK_LAUNCH();
     ConvArgs a{};
     a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps; a.ty0 = ty0;
-    const int lds = 340 * 64 * sizeof(T);
-    static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, 340 * 64 * sizeof(T)), true);
+    const int lds = CONV_HALO * 64 * sizeof(T);
+    static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, CONV_HALO * 64 * sizeof(T)), true);
     (void)once;
     {
-      ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * 8) * W * 9 * 64 * 64);
-      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / 8 - ty0, B), dim3(256), lds, st, a);
+      ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * CONV_TR) * W * 9 * 64 * 64);
+      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / CONV_TR - ty0, B), dim3(256), lds, st, a);
     }
     CHECK_LAUNCH();
     if (ph0 > 0) {  // token rows < ph0 receive exactly zero
