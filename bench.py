@@ -60,9 +60,9 @@ def cpu_baseline(geometry, threads: int) -> dict:
 
 def gemm_hbm_traffic_per_launch() -> float | None:
     """HBM bytes per GEMM launch (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc
-    summary of this same command (`profiles/r1_step2_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
+    summary of this same command (`profiles/r1_step6_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
     passes cannot run inside the timed process, so the figure is measured offline and reported here."""
-    f = ROOT / "profiles" / "r1_step2_pmc_summary.json"
+    f = ROOT / "profiles" / "r1_step6_pmc_summary.json"
     if not f.exists():
         return None
     n = b = 0.0
@@ -120,7 +120,10 @@ def main() -> None:
     g = getattr(SegGptGeometry, args.geometry)()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     log(f"rank {rank}/{world}: building {args.geometry} ({args.dtype}) on {dev}")
-    model = SegGptNative(synth_state_dict(g, seed=0, device=dev), g, device=dev, dtype=dtype)
+    # BSG_BENCH_CPU_WEIGHTS: build the (bit-identical) synthetic weights on the host -- under rocprofv3 --pmc the
+    # thousands of tiny generator kernels would otherwise dominate the profiling run
+    wdev = torch.device("cpu") if os.environ.get("BSG_BENCH_CPU_WEIGHTS") else dev
+    model = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dtype)
     log("model ready")
     B, P = args.batch, args.prompts
     Hh, W = g.image_size[0] // 2, g.image_size[1]
