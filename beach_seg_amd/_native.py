@@ -48,6 +48,9 @@ def load():
     if not _LIB_PATH.exists():
         raise NativeError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it carries its own HIP runtime (torch/lib/libamdhip64.so).  If this library were loaded before torch,
+    # the process would hold two runtimes and bsg_create would see no device ("no HIP device") although torch does.
+    import torch  # noqa: F401
     lib = C.CDLL(os.fspath(_LIB_PATH))
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     lib.bsg_last_error.restype = C.c_char_p
