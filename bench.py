@@ -111,11 +111,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    dev = torch.device(f"cuda:{local_rank}")
+    # BSG_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device); the reported number is meaningless then.
+    rehearse = bool(os.environ.get("BSG_BENCH_REHEARSE"))
+    dev = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     g = getattr(SegGptGeometry, args.geometry)()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
