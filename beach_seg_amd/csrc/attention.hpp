@@ -688,9 +688,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     float* wT = a.relwT + sh * 32 * npad + q0 + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) wT[(long)acc32_row(r, h) * npad] = real ? rwv[r] : -INFINITY;
-    if (real) {
-      float* hT = a.relhT + sh * a.hp * npad + q0 + col;
-      for (int kh = h; kh < a.hp; kh += 2) hT[(long)kh * npad] = relh_q[kh];
+    float* hT = a.relhT + sh * a.hp * npad + q0 + col;
+    for (int kh = h; kh < a.hp; kh += 2) hT[(long)kh * npad] = real ? relh_q[kh] : 0.f;
+    if (!real && h == 0) {  // tail columns of the per-query statistics: finite whatever the workspace held before
+      a.lse2[sh * npad + q0 + col] = 0.f;
+      a.delta[sh * npad + q0 + col] = 0.f;
     }
   }
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // Here the KEY is on the lane (S = Q K^T un-swapped), so P and dS accumulators are the B operands of
 // dV^T += dO^T P and dK^T += Q^T dS.  Bias / lse2 / delta arrive in query-slot-major ("T") layouts:
 //   relwT [S][nh][32 kw][Hp*32],  relhT [S][nh][Hp key rows][Hp*32],  lse2/delta [S][nh][Hp*32], column = token;
-//   columns N .. 64 ceil(N/64) - 1 of relwT hold -inf (P = 0 there), of the others 0.
+//   columns N .. 64 ceil(N/64) - 1 of relwT hold -inf (P = 0 there), of the others 0 (all written by the dQ kernel).
 struct AttnBwdKvArgs {
   const void* k; const void* v; const void* q; const void* dout;  // row-major T (q/k/v with ld, dout with ldo)
   const void* qt; const void* dot;                                // [S][nh][64][Hp*32], column = token (f32 path)

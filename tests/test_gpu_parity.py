@@ -264,6 +264,22 @@ def test_tile_front_end_bit_exact_vs_pillow(golden_dir):
         ops.tile_frontend(mosaic.float(), torch.from_numpy(rec["boxes112"]).to(DEV), 112, 448)
 
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_results_do_not_depend_on_workspace_contents(golden_dir, dtype):
+    """The ABI asks for a zeroed workspace; this checks how much actually depends on it: with every workspace byte set
+    to 0xFF (NaN patterns in every dtype) before the call, forward and backward must give bit-identical results, on a
+    grid whose token count is not a multiple of the dK/dV query tile (tail columns exist)."""
+    rec = np.load(golden_dir / "tiny_e2e.npz")
+    clean = run_case("tiny", rec, 2, dtype)
+    model = model_for("tiny", int(rec["wseed"]), dtype)
+    for key in list(model._ws):
+        model._ws[key].fill_(0xFF)
+    dirty = run_case("tiny", rec, 2, dtype)
+    assert torch.equal(clean[0], dirty[0]) and clean[1] == dirty[1]
+    assert torch.equal(clean[2], dirty[2]), float((clean[2] - dirty[2]).abs().max())
+
+
 # ------------------------------------------------------------------- full-size, size-independent properties
 def test_full_geometry_batch_invariance_and_linearity():
     """At the BASELINE geometry (ViT-L, bf16): a sample's prediction does not depend on its batch (bit-exact),
