@@ -28,7 +28,7 @@ struct AttnArgs {
   const void* dout;  // backward: dO, T [S*N][ldo]
   const void* rel_cat;   // T [LH + LW][64]: rel_pos_h rows at 0.., rel_pos_w rows at LH = roundup16(2 Hp)..
   const void* rel_catT;  // backward: T [64][LH + LW]
-  float* relhT;          // backward, WRITTEN by the dQ kernel for dK/dV: [S][nh][Hp][Hp*32], column = token
+  float* relhT;          // backward, WRITTEN by the dQ kernel for dK/dV: [S][nh][Hp][Hp*32], column = token; holds relh * c2 - lse2
   float* relwT;          // same: [S][nh][32][Hp*32]; -inf for kw >= Wp and in columns N .. 64 ceil(N/64) - 1
   void* out;          // fwd: O, T [S*N][ldo]
   long ldo;
@@ -688,8 +688,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     float* wT = a.relwT + sh * 32 * npad + q0 + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) wT[(long)acc32_row(r, h) * npad] = real ? rwv[r] : -INFINITY;
+    // row bias pre-folded with the softmax statistics: relhT[kh][q] = relh[q][kh] * c2 - lse2[q], so that the dK/dV
+    // kernel's exponent is one fma on top of an accumulator that starts from relwT alone
     float* hT = a.relhT + sh * a.hp * npad + q0 + col;
-    for (int kh = h; kh < a.hp; kh += 2) hT[(long)kh * npad] = real ? relh_q[kh] : 0.f;
+    const float c2p = a.scale * 1.44269504088896340736f, lsep = a.lse2[sh * npad + q];
+    for (int kh = h; kh < a.hp; kh += 2) hT[(long)kh * npad] = real ? fmaf(relh_q[kh], c2p, -lsep) : 0.f;
     if (!real && h == 0) {  // tail columns of the per-query statistics: finite whatever the workspace held before
       a.lse2[sh * npad + q0 + col] = 0.f;
       a.delta[sh * npad + q0 + col] = 0.f;
@@ -834,7 +837,7 @@ struct AttnBwdKvArgs {
   const void* k; const void* v; const void* q; const void* dout;  // row-major T (q/k/v with ld, dout with ldo)
   const void* qt; const void* dot;                                // [S][nh][64][Hp*32], column = token (f32 path)
   long ld, ldo;
-  const float* relwT; const float* relhT; const float* lse2; const float* delta;  // delta holds MINUS rowsum(dO * O)
+  const float* relwT; const float* relhT; const float* lse2; const float* delta;  // delta = MINUS rowsum(dO * O); relhT = relh * c2 - lse2
   void* dk; void* dv;  // T, row stride ld
   int S, nh, N, hp, wp;
   int prio;
@@ -945,16 +948,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
     for (int qa = 0; qa < 2; ++qa) {
       f32x16 st, dp;
-      f32x4 lse4[4], dl4[4];
+      f32x4 rhl4[4];  // relh * c2 - lse2 of this wave's key row, per query slot (pre-folded by the dQ kernel)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = qa * 8 + 2 * i + h;  // 16-byte chunk holding query slots qa*32 + 8i + 4h .. +3
-        lse4[i] = *(const f32x4*)(st_l + c * 16);
-        dl4[i] = *(const f32x4*)(st_l + 256 + c * 16);
-        const f32x4 rh = *(const f32x4*)(st_l + (2 + wave) * 256 + c * 16);
+        const f32x4 dl4 = *(const f32x4*)(st_l + 256 + c * 16);
+        rhl4[i] = *(const f32x4*)(st_l + (2 + wave) * 256 + c * 16);
         const f32x4 rw = *(const f32x4*)(rw_l + ((c ^ (col & 15)) << 4));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j] + rh[j]; dp[4 * i + j] = dl4[i][j]; }  // dP accumulates onto -delta
+        for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j]; dp[4 * i + j] = dl4[j]; }  // S starts from relwT, dP from -delta
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
@@ -964,7 +966,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // padded key lanes / padded query slots carry relwT = -inf: P = 0 there without any masking
-        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse4[r >> 2][r & 3]));
+        const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c2, rhl4[r >> 2][r & 3]));
         st[r] = p;                                   // P
         dp[r] = p * dp[r];                           // dS = P (dP - delta)
       }
