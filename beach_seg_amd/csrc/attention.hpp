@@ -38,7 +38,6 @@ struct AttnArgs {
   void* dk;
   void* dv;
   int S, nh, N, hp, wp;
-  int prio;  // experiment: wave priority pattern (0 = none)
   float scale;
 };
 
@@ -52,21 +51,6 @@ DEVI void attn_block_ids(int nx, int nh, int S, int& x, int& head, int& s) {
   s = t / nh;
 }
 
-
-// experiment knob: give co-resident waves different issue priority so they de-phase (one in its MFMA segment
-// while the other is in softmax VALU) instead of convoying through both at half speed.
-DEVI void attn_set_prio(int mode, int wave) {
-  const int b = blockIdx.x;
-  int p = 0;
-  if (mode == 1) p = b & 1;
-  else if (mode == 2) p = (b >> 3) & 1;
-  else if (mode == 3) p = (b >> 8) & 1;
-  else if (mode == 4) p = wave >= 4;
-  else if (mode == 5) p = (b >> 3) & 3;
-  if (p == 1) __builtin_amdgcn_s_setprio(1);
-  else if (p == 2) __builtin_amdgcn_s_setprio(2);
-  else if (p == 3) __builtin_amdgcn_s_setprio(3);
-}
 
 // LDS chunk swizzle (position = chunk ^ swz(row)).  128-byte (bf16) rows are read two ways: along the row
 // (ds_read_b128, lane = row) and TRANSPOSED (ds_read_b64_tr_b16, four rows x 64 bytes per half-wave).  With
@@ -313,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
-  attn_set_prio(a.prio, wave);
   const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const long sh = (long)s * a.nh + head;
@@ -652,7 +635,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
-  attn_set_prio(a.prio, wave);
   const int q0 = bx * 128 + wave * 32;
   const int q = min(q0 + col, a.N - 1);
   const long sh = (long)s * a.nh + head;
@@ -840,7 +822,6 @@ struct AttnBwdKvArgs {
   const float* relwT; const float* relhT; const float* lse2; const float* delta;  // delta = MINUS rowsum(dO * O); relhT = relh * c2 - lse2
   void* dk; void* dv;  // T, row stride ld
   int S, nh, N, hp, wp;
-  int prio;
   float scale;
 };
 
@@ -879,7 +860,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
-  attn_set_prio(a.prio, wave);
   const int nt = (a.N + 63) >> 6;
   const int kr0 = bx * 8;
   const bool wave_valid = kr0 + wave < a.hp;

@@ -261,8 +261,6 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.relhT = relh_s; a.out = attn_o;
       a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static const int fprio = getenv("BSG_ATTN_PRIO_FWD") ? atoi(getenv("BSG_ATTN_PRIO_FWD")) : 0;
-      a.prio = fprio;
       static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
       static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024),
                            allow_lds(attn_fwd_sp_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_sp_kernel<T, can_tr>, 160 * 1024), true);
@@ -466,8 +464,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.rel_cat = m->lw(l, 18);
       a.rel_catT = m->lw(l, 19); a.relhT = relhT; a.relwT = relwT; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static const int qprio = getenv("BSG_ATTN_PRIO_DQ") ? atoi(getenv("BSG_ATTN_PRIO_DQ")) : 0;
-      a.prio = qprio;
       static bool once = (allow_lds(attn_bwd_dq_kernel<T, false>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, can_tr>, 160 * 1024), true);
       (void)once;
       {
@@ -482,8 +478,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
-      static const int kprio = getenv("BSG_ATTN_PRIO_DKV") ? atoi(getenv("BSG_ATTN_PRIO_DKV")) : 0;
-      k.prio = kprio;
       static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, false>, 2 * DkvK<T, false>::STAGE),
                            allow_lds(attn_bwd_dkv_kernel<T, can_tr>, 2 * DkvK<T, can_tr>::STAGE), true);
       (void)once2;
