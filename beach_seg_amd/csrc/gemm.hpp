@@ -394,6 +394,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
 // region it overwrites.  One counted `s_waitcnt vmcnt(4)` per phase (two quarters stay in flight across the
 // barriers; never vmcnt(0) in the loop), raw s_barrier, MFMA clusters under s_setprio.  Waves 4-7 run one barrier
 // behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while the other issues reads and DMA.
+#ifdef BSG_DIAG_STAMPS
+__device__ long long bsg_stamps[256 * 4];
+#endif
 template <typename T, int AMODE, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   constexpr int EPC = Traits<T>::EPC;
@@ -413,6 +416,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   const bool wm1 = (wave >> 2) == 1;
   bool primed = false;
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+#ifdef BSG_DIAG_STAMPS
+  const long long st_tile_start = __builtin_amdgcn_s_memtime();
+#endif
   int bid = xcd_remap(vb, nwg);
   // groups of 4 row tiles: the blocks resident on one XCD at a time share 4 activation panels and a few weight panels
   const int GM = g.group_m > 0 ? g.group_m : 4;
@@ -545,6 +551,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     }
   }
   if (wm == 0) asm volatile("s_barrier" ::: "memory");  // balance the stagger
+#ifdef BSG_DIAG_STAMPS
+  const long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
   primed = false;
   if (vb + (int)gridDim.x < nwg && !(nk & 1)) {
     // every wave is past its last LDS read of buffer 0 (K tile nk - 2); request K tile 0 of the next output tile into it
@@ -589,6 +598,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   }
   gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk);
   gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk);
+#ifdef BSG_DIAG_STAMPS
+  {
+    const long long st_issued = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long st_done = __builtin_amdgcn_s_memtime();
+    if (vb == (int)blockIdx.x + (int)gridDim.x && tid == 0 && blockIdx.x < 256) {  // second tile of each workgroup (steady state)
+      bsg_stamps[blockIdx.x * 4 + 0] = st_loop_end - st_tile_start;
+      bsg_stamps[blockIdx.x * 4 + 1] = st_issued - st_loop_end;
+      bsg_stamps[blockIdx.x * 4 + 2] = st_done - st_issued;
+    }
+  }
+#endif
   (void)wm1;
   }  // tile loop
 }

@@ -719,7 +719,21 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
   if (getenv("BSG_GEMM_LDO0")) g.ldo = 0;  // diagnostics: every row lands on row 0 (stores stay in L2)
   if (nostore) { gemm<bf16_t, A_PLAIN, EPI_NONE>(&dummy, g, st); CHECK_LAUNCH(); return 0; }
   if (dtype == BSG_DTYPE_F32) { if (bias) gemm<float, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<float, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
+#ifdef BSG_DIAG_STAMPS  // the diagnostic build times the GELU epilogue through the bias entry
+  else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS_GELU>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
+#else
   else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
+#endif
+#ifdef BSG_DIAG_STAMPS
+  {
+    (void)hipStreamSynchronize(st);
+    static long long h[256 * 4];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(bsg_stamps), sizeof(h));
+    double a = 0, b = 0, c = 0;
+    for (int i = 0; i < 256; ++i) { a += h[4 * i]; b += h[4 * i + 1]; c += h[4 * i + 2]; }
+    fprintf(stderr, "[stamps] per tile (second tile of each workgroup, shader cycles): main loop %.0f, epilogue to last store issued %.0f, store drain %.0f\n", a / 256, b / 256, c / 256);
+  }
+#endif
   CHECK_LAUNCH();
   return 0;
 }

@@ -1,0 +1,14 @@
+import sys, torch
+sys.path.insert(0, '/root/repo')
+from beach_seg_amd import ops
+dev = torch.device("cuda:0")
+for M, N, K in [(100352, 4096, 1024), (100352, 1024, 1024), (100352, 1024, 4096)]:
+    a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+    w = (torch.rand(N, K, device=dev) * 2 - 1).bfloat16()
+    b = torch.zeros(N, device=dev)
+    for _ in range(3): ops.gemm_nt(a, w)
+    print(f"plain M={M} N={N} K={K}", file=sys.stderr, flush=True)
+    ops.gemm_nt(a, w)
+    for _ in range(3): ops.gemm_nt(a, w, b)
+    print(f"bias+gelu M={M} N={N} K={K}", file=sys.stderr, flush=True)
+    ops.gemm_nt(a, w, b)
