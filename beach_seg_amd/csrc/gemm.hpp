@@ -414,6 +414,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   // the next output tile is requested BEFORE the epilogue of the current one, so its HBM/L2 latency and the
   // workgroup launch disappear behind the store burst.
   const bool wm1 = (wave >> 2) == 1;
+#ifdef BSG_DIAG_STAMPS
+  const long long st_wg_start = __builtin_amdgcn_s_memtime(), st_wg_real = __builtin_amdgcn_s_memrealtime();
+#endif
   bool primed = false;
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
 #ifdef BSG_DIAG_STAMPS
@@ -612,6 +615,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 #endif
   (void)wm1;
   }  // tile loop
+#ifdef BSG_DIAG_STAMPS
+  if (tid == 0 && blockIdx.x < 256)  // shader cycles per 100 MHz reference tick over the workgroup's lifetime, x 1000
+    bsg_stamps[blockIdx.x * 4 + 3] = (__builtin_amdgcn_s_memtime() - st_wg_start) * 1000 / max(1LL, (long long)(__builtin_amdgcn_s_memrealtime() - st_wg_real));
+#endif
 }
 
 template <typename T, int AMODE, int EPI>

@@ -729,9 +729,9 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
     (void)hipStreamSynchronize(st);
     static long long h[256 * 4];
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(bsg_stamps), sizeof(h));
-    double a = 0, b = 0, c = 0;
-    for (int i = 0; i < 256; ++i) { a += h[4 * i]; b += h[4 * i + 1]; c += h[4 * i + 2]; }
-    fprintf(stderr, "[stamps] per tile (second tile of each workgroup, shader cycles): main loop %.0f, epilogue to last store issued %.0f, store drain %.0f\n", a / 256, b / 256, c / 256);
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int i = 0; i < 256; ++i) { a += h[4 * i]; b += h[4 * i + 1]; c += h[4 * i + 2]; d += h[4 * i + 3]; }
+    fprintf(stderr, "[stamps] per tile (second tile of each workgroup, shader cycles): main loop %.0f, epilogue to last store issued %.0f, store drain %.0f; shader clock %.2f GHz\n", a / 256, b / 256, c / 256, d / 256 * 1e-4);
   }
 #endif
   CHECK_LAUNCH();
