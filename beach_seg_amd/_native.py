@@ -19,7 +19,7 @@ SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend", "bsg_decode_hf",
 )
 
 
@@ -75,6 +75,7 @@ def load():
     lib.bsg_adamw_step.argtypes = [vp, i, C.c_long, vp, vp, vp, vp, vp, vp, vp, vp, f, f, f, f, f, f]
     lib.bsg_vote_paste.argtypes = [vp, i, vp, i, i, i, vp, vp, i, i, i]
     lib.bsg_vote_argmax.argtypes = [vp, vp, C.c_long, i, vp]
+    lib.bsg_decode_hf.argtypes = [vp, i, i, i, i, vp, vp, f3, f3, vp]
     lib.bsg_tile_frontend.argtypes = [vp, vp, i, i, i, vp, i, i, vp, vp, i, f3, f3, vp, vp]
     lib.bsg_profile_enable.argtypes = [vp, i]
     lib.bsg_profile_read.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]

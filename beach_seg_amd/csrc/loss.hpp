@@ -92,6 +92,32 @@ __global__ void decode_argmin_kernel(const float* __restrict__ pred, const float
   if (out_u8) out_u8[i] = (uint8_t)best;
 }
 
+// HF decode (`SegGptImageProcessor.post_process_semantic_segmentation`, HF:image_processing_seggpt.py:300-332; used by
+// src/predict_no_prompt.py:297-303): bottom half, x * std + mean, clip(x * 255, 0, 255), squared distance to the integer
+// palette (K, 3), first arg-min.  Every product / sum is its own IEEE operation in torch's order.
+__global__ void decode_hf_kernel(const float* __restrict__ pred, const float* __restrict__ palette,
+                                 uint8_t* __restrict__ out_u8, int B, int H, int W, int K, float m0, float m1, float m2,
+                                 float s0, float s1, float s2) {
+  const long hw = (long)H * W, n = (long)B * hw;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = i / hw;
+  const long p = i % hw;
+  const float* pr = pred + (long)b * 3 * 2 * hw + hw + p;
+  const float v0 = fminf(fmaxf(__fmul_rn(__fadd_rn(__fmul_rn(pr[0], s0), m0), 255.0f), 0.f), 255.f);
+  const float v1 = fminf(fmaxf(__fmul_rn(__fadd_rn(__fmul_rn(pr[2 * hw], s1), m1), 255.0f), 0.f), 255.f);
+  const float v2 = fminf(fmaxf(__fmul_rn(__fadd_rn(__fmul_rn(pr[4 * hw], s2), m2), 255.0f), 0.f), 255.f);
+  int best = 0;
+  float bd = INFINITY;
+  for (int k = 0; k < K; ++k) {
+    const float* c = palette + k * 3;
+    const float d0 = __fsub_rn(v0, c[0]), d1 = __fsub_rn(v1, c[1]), d2 = __fsub_rn(v2, c[2]);
+    const float d = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2));
+    if (d < bd) { bd = d; best = k; }
+  }
+  out_u8[i] = (uint8_t)best;
+}
+
 // AdamW step on the active prompts (torch.optim.AdamW: decoupled decay, bias correction, eps outside sqrt-hat).
 // idx[a] = prompt row; step_sizes[a] = lr / (1 - beta1^t), bc2_sqrts[a] = sqrt(1 - beta2^t) with t that
 // parameter's own step count (torch keeps one `step` per Parameter and skips Parameters without a gradient);

@@ -748,6 +748,17 @@ int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int
   return 0;
 }
 
+int bsg_decode_hf(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette,
+                  const float* mean3, const float* std3, uint8_t* out_u8) {
+  if (!pred || !palette || !mean3 || !std3 || !out_u8) return fail("bsg_decode_hf: null argument");
+  if (batch <= 0 || h <= 0 || w <= 0 || K <= 0 || K > 255) return fail("bsg_decode_hf: bad geometry");
+  const long n = (long)batch * h * w;
+  hipLaunchKernelGGL(decode_hf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, palette,
+                     out_u8, batch, h, w, K, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bsg_tile_frontend(void* stream, const uint8_t* mosaic, int mh, int mw, int n_crops, const int32_t* crops, int crop,
                       int S, const int32_t* coef, const int32_t* bounds, int kmax, const float* mean3,
                       const float* std3, float* out, uint8_t* out_u8) {

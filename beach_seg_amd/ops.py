@@ -188,6 +188,42 @@ def tile_frontend(mosaic: torch.Tensor, crops: torch.Tensor, crop_size: int, out
     return (out, u8) if return_u8 else out
 
 
+def post_process_semantic_segmentation(pred_masks: torch.Tensor, num_labels: int, target_sizes=None,
+                                       mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> list[torch.Tensor]:
+    """`SegGptImageProcessor.post_process_semantic_segmentation(outputs, target_sizes, num_labels)`
+    (`HF:image_processing_seggpt.py:300-332`) as the reference's few-shot caller uses it
+    (`src/predict_no_prompt.py:297-303`): pred_masks f32 (B,3,2H,W) -> list of B int64 maps, (H,W) or the target sizes.
+    The decode runs in one HIP kernel at full resolution; the nearest resize (F.interpolate's index rule
+    floor(dst * in / out)) commutes with the per-pixel arg-min and is applied to the class map."""
+    import ctypes as C
+
+    from .ml_util import build_palette
+    _need_gpu(pred_masks)
+    B, ch, H2, W = pred_masks.shape
+    if ch != 3 or H2 % 2:
+        raise ValueError("pred_masks must be (B, 3, 2H, W)")
+    if target_sizes is not None and len(target_sizes) != B:
+        raise ValueError("Make sure that you pass in as many target sizes as the batch dimension of the logits")
+    lib = N.load()
+    pred = pred_masks.detach().float().contiguous()
+    pal = torch.tensor(build_palette(num_labels), dtype=torch.float32, device=pred.device)
+    out = torch.empty((B, H2 // 2, W), dtype=torch.uint8, device=pred.device)
+    f3 = C.c_float * 3
+    with torch.cuda.device(pred.device):
+        N.check(lib.bsg_decode_hf(_stream(), B, H2 // 2, W, num_labels + 1, _ptr(pred), _ptr(pal), f3(*mean), f3(*std),
+                                  _ptr(out)))
+    res = []
+    for i in range(B):
+        m = out[i]
+        if target_sizes is not None:
+            th, tw = target_sizes[i]
+            ys = (torch.arange(th, device=m.device) * (m.shape[0] / th)).floor().long().clamp_(max=m.shape[0] - 1)
+            xs = (torch.arange(tw, device=m.device) * (m.shape[1] / tw)).floor().long().clamp_(max=m.shape[1] - 1)
+            m = m[ys][:, xs]
+        res.append(m.long())
+    return res
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16 or both f32."""
     _need_gpu(a, w, bias)

@@ -79,3 +79,17 @@ def grid_crops(height: int, width: int, crop_size: int, stride: int | None = Non
     xs = list(range(0, width, stride))
     ys = list(range(0, height, stride))
     return torch.tensor([[x, y, x + crop_size, y + crop_size] for y in ys for x in xs], dtype=torch.int32)
+
+
+@torch.no_grad()
+def ensemble_predict(net, pixel_values: torch.Tensor, prompt_pixel_values: torch.Tensor, prompt_masks: torch.Tensor,
+                     num_classes: int, crop_size: int) -> torch.Tensor:
+    """One crop of the few-shot loop of `/root/reference/src/predict_no_prompt.py:283-304`: the query repeated once per
+    prompt (K, 3, S, S), `feature_ensemble=True` forward, mean of `pred_masks` over the K prompts, HF post-process decode
+    to (crop_size, crop_size) with `num_labels = num_classes - 1`.  `net` is the object `load_model` returns
+    (`SegGptNative`).  Returns the int64 class map on the device; nodata masking and the vote are the caller's
+    (`:302-304`, `Accumulator.update`)."""
+    out = net(pixel_values=pixel_values, prompt_pixel_values=prompt_pixel_values, prompt_masks=prompt_masks,
+              embedding_type="instance", feature_ensemble=True)
+    pred = out.pred_masks.mean(dim=0).unsqueeze(0)
+    return ops.post_process_semantic_segmentation(pred, num_classes - 1, [(crop_size, crop_size)])[0]

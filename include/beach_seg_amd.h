@@ -107,6 +107,13 @@ int bsg_loss_fwd_bwd(void* stream, int batch, int h, int w, const float* pred, c
 int bsg_decode_argmin(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette_norm,
                       int64_t* out_i64, uint8_t* out_u8);
 
+/* HF decode used by the reference's few-shot caller (src/predict_no_prompt.py:297-303 ->
+ * SegGptImageProcessor.post_process_semantic_segmentation, HF:image_processing_seggpt.py:300-332): bottom half of
+ * pred f32 (B,3,2h,w), x * std + mean, clip(x * 255, 0, 255), arg-min of the squared distance to palette f32 (K,3)
+ * (integer colours, shared by the batch) -> out u8 (B,h,w). */
+int bsg_decode_hf(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette,
+                  const float* mean3, const float* std3, uint8_t* out_u8);
+
 /* prepare_prompt's gather (src/model.py:197 stack + data.py:224 Normalize) and its backward (scatter-add of
  * grad / std into the rows of the flat prompt-gradient buffer). params/grads: f32 (P,3,h,w); idx: i32 (B). */
 int bsg_prompt_gather(void* stream, int batch, int h, int w, const float* params, const int32_t* idx,

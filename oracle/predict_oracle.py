@@ -38,3 +38,37 @@ def accumulate(counter: np.ndarray, crop: tuple[int, int, int, int], one_hot_pre
 def vote_argmax(counter: np.ndarray) -> np.ndarray:
     """`np.argmax(self.current_pred_counter, axis=2)` (`src/predict.py:100`)."""
     return np.argmax(counter, axis=2)
+
+
+def hf_build_palette(num_labels: int):
+    """`HF:image_processing_seggpt.py` build_palette: class 0 black, then a base^3 lattice walked from white downwards."""
+    base = int(num_labels ** (1 / 3)) + 1
+    margin = 256 // base
+    out = [(0, 0, 0)]
+    for loc in range(num_labels):
+        r, g, b = loc // base ** 2, (loc % base ** 2) // base, loc % base
+        out.append((255 - r * margin, 255 - g * margin, 255 - b * margin))
+    return out
+
+
+def hf_post_process(pred_masks, num_labels: int, target_size=None):
+    """`SegGptImageProcessor.post_process_semantic_segmentation` (`HF:image_processing_seggpt.py:300-332`), the decode the
+    reference's second caller uses (`/root/reference/src/predict_no_prompt.py:297-303`): bottom half of the canvas ->
+    un-normalise (x * std + mean) -> clip(x * 255, 0, 255) -> optional nearest resize -> arg-min of the squared distance
+    to the integer palette.  pred_masks: torch f32 (B, 3, 2H, W) -> list of int64 (h, w)."""
+    import torch
+
+    std = torch.tensor([0.229, 0.224, 0.225])
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    m = pred_masks[:, :, pred_masks.shape[2] // 2:, :]
+    m = (m.permute(0, 2, 3, 1) * std + mean).permute(0, 3, 1, 2)
+    m = torch.clip(m * 255, 0, 255)
+    pal = torch.tensor(hf_build_palette(num_labels), dtype=torch.float).view(1, 1, num_labels + 1, 3)
+    out = []
+    for mask in m:
+        if target_size is not None:
+            mask = torch.nn.functional.interpolate(mask.unsqueeze(0), size=target_size, mode="nearest")[0]
+        c, h, w = mask.shape
+        d = torch.pow(mask.permute(1, 2, 0).view(h, w, 1, c) - pal, 2).sum(-1)
+        out.append(d.argmin(-1))
+    return out

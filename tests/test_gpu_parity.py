@@ -280,6 +280,22 @@ def test_results_do_not_depend_on_workspace_contents(golden_dir, dtype):
     assert torch.equal(clean[2], dirty[2]), float((clean[2] - dirty[2]).abs().max())
 
 
+
+def test_hf_post_process_decode_bit_exact(golden_dir):
+    """bsg_decode_hf / ops.post_process_semantic_segmentation against the transformers post-processor's own output:
+    un-normalise, clip, palette arg-min at full size, with target sizes, and after the mean over prompts."""
+    rec = np.load(golden_dir / "hf_postprocess.npz")
+    pred, nl = torch.from_numpy(rec["pred"]).to(DEV), int(rec["num_labels"])
+    full = ops.post_process_semantic_segmentation(pred, nl)
+    assert np.array_equal(torch.stack(full).cpu().numpy(), rec["full"])
+    small = ops.post_process_semantic_segmentation(pred, nl, [(12, 10)] * pred.shape[0])
+    assert np.array_equal(torch.stack(small).cpu().numpy(), rec["small"])
+    ens = ops.post_process_semantic_segmentation(pred.mean(dim=0).unsqueeze(0), nl, [(16, 16)])
+    assert np.array_equal(torch.stack(ens).cpu().numpy(), rec["ens"])
+    with pytest.raises(ValueError):
+        ops.post_process_semantic_segmentation(pred, nl, [(12, 10)])
+
+
 # ------------------------------------------------------------------- full-size, size-independent properties
 def test_full_geometry_batch_invariance_and_linearity():
     """At the BASELINE geometry (ViT-L, bf16): a sample's prediction does not depend on its batch (bit-exact),
@@ -317,6 +333,15 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
                     prompt_pixel_values=torch.from_numpy(rec["prompt_pixel_values"]).to(DEV),
                     prompt_masks=torch.from_numpy(rec["prompt_masks"]).to(DEV), feature_ensemble=True)
     assert relmax(out.pred_masks, rec["pred"]) < TOL[dtype]["t"]
+    if dtype == torch.float32:  # the whole few-shot crop step of src/predict_no_prompt.py:283-301 against the oracle's decode
+        from beach_seg_amd.predict import ensemble_predict
+        from oracle import predict_oracle as PO
+
+        got = ensemble_predict(model, torch.from_numpy(rec["pixel_values"]).to(DEV),
+                               torch.from_numpy(rec["prompt_pixel_values"]).to(DEV),
+                               torch.from_numpy(rec["prompt_masks"]).to(DEV), num_classes=4, crop_size=16)
+        want = PO.hf_post_process(torch.from_numpy(rec["pred"]).mean(0, keepdim=True), 3, (16, 16))[0]
+        assert (got.cpu() == want).float().mean().item() > 0.99  # pred differs from HF's by ~1e-6: near-ties may flip
 
 
 def test_wide_grid_and_wide_encoder_vs_oracle():

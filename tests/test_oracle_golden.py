@@ -136,3 +136,16 @@ def test_tile_front_end_vs_pillow_and_reference(golden_dir):
     for box, want in zip(rec["pc_boxes"], rec["pc_out"]):
         assert np.array_equal(padded_crop(rec["pc_src"], tuple(int(v) for v in box)), want)
         assert np.array_equal(FO.padded_crop(rec["pc_src"], box, 5) if box[0] >= 0 and box[1] >= 0 else want, want)
+
+
+def test_hf_post_process_decode(golden_dir):
+    """Oracle restatement of SegGptImageProcessor.post_process_semantic_segmentation (the decode of the reference's
+    few-shot caller) against the transformers class itself (fixture from oracle/gen_golden_postprocess.py)."""
+    from beach_seg_amd.ml_util import build_palette
+
+    rec = np.load(golden_dir / "hf_postprocess.npz")
+    pred, nl = torch.from_numpy(rec["pred"]), int(rec["num_labels"])
+    assert PO.hf_build_palette(nl) == [tuple(int(v) for v in row) for row in rec["palette"]] == build_palette(nl)
+    assert np.array_equal(torch.stack(PO.hf_post_process(pred, nl)).numpy(), rec["full"])
+    assert np.array_equal(torch.stack(PO.hf_post_process(pred, nl, (12, 10))).numpy(), rec["small"])
+    assert np.array_equal(torch.stack(PO.hf_post_process(pred.mean(0, keepdim=True), nl, (16, 16))).numpy(), rec["ens"])
