@@ -434,191 +434,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------- forward, software-pipelined
-// The kernel above runs S^T MFMAs -> softmax VALU -> PV MFMAs strictly in turn inside a wave, and two waves per SIMD
-// do not hide that (measured: per key tile the wave spends about the SUM of its matrix time and its VALU issue time).
-// Here the dependent chain is cut across tiles and the two streams are interleaved BY HAND in one basic block:
-// eight slices per tile, each = operand reads, the exponentials of two accumulator rows of tile t, then one S^T MFMA
-// of tile t+1 and (second half) one PV MFMA of tile t, fenced by sched_barrier so the compiler keeps the order.  The
-// last PV k-step runs under the running-max update of tile t+1.  K tiles arrive two ahead (3-deep ring), V one ahead.
-template <typename T, bool TR>
-__global__ __launch_bounds__(256, 2) void attn_fwd_sp_kernel(AttnArgs a) {
-  typedef typename Traits<T>::Chunk Chunk;
-  typedef AttnK<T> C;
-  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
-  constexpr int NSL = 8;                       // slices per tile
-  constexpr int NSC = 2 * C::KS_D / NSL;       // S^T MFMA calls per slice (bf16 1, f32 2)
-  constexpr int WIN = NSL / C::KS_B;           // slices a PV k-step is spread over (bf16 4, f32 2)
-  constexpr int NPC = 4 / WIN;                 // PV MFMA calls per slice inside a window (bf16 1, f32 2)
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // K ring [3][TILE] | V ring [2][TILE] | relh tables
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bx, head, s;
-  attn_block_ids((a.N + 127) / 128, a.nh, a.S, bx, head, s);
-  const int q0 = bx * 128 + wave * 32;
-  const int q = min(q0 + col, a.N - 1);
-  const long sh = (long)s * a.nh + head;
-  const int npad = a.hp * 32;
-  const char* kbase = (const char*)a.k + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
-  const char* vtbase = TR ? (const char*)a.v + ((long)s * a.N * a.ld + head * 64) * sizeof(T)
-                          : (const char*)a.vt + sh * 64 * npad * sizeof(T);
-  char* kring = smem;
-  char* vring = smem + 3 * C::TILE;
-
-  Chunk qf[C::KS_D];
-  {
-    const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
-#pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
-  }
-  f32x16 rwv;
-  float* relh_q = (float*)(smem + 5 * C::TILE) + (wave * 32 + col) * relh_stride(a.hp);
-  const bool active = q0 < a.N;  // wave-uniform: a wave past the last query only helps with the DMA and the barriers
-  if (active)
-    relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, q / a.wp, q % a.wp, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
-                          1.0f / a.scale, (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
-  __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
-  const float c2 = a.scale * 1.44269504088896340736f;
-  float m = -INFINITY, l = 0.f;
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
-
-  const int nt = a.hp >> 1;
-  unsigned koff[TileDma<T>::IPW], voff[TileDma<T>::IPW];
-  const long es = sizeof(T), kstep = 2L * a.wp * a.ld * es, vstep = TR ? kstep : 64 * es;
-  dma_tile_offsets<T>(koff, wave, lane, [&](int r) { return (long)slot_token(r >> 5, r & 31, a.wp) * a.ld * es; });
-  if constexpr (TR) {
-#pragma unroll
-    for (int i = 0; i < TileDma<T>::IPW; ++i) voff[i] = koff[i];
-  } else {
-    dma_tile_offsets<T>(voff, wave, lane, [&](int r) { return (long)r * npad * es; });
-  }
-  auto issue_k = [&](int t) { dma_tile_issue<T>(kring + (t % 3) * C::TILE, wave, kbase + t * kstep, koff); };
-  auto issue_v = [&](int t) { dma_tile_issue<T>(vring + (t & 1) * C::TILE, wave, vtbase + t * vstep, voff); };
-
-  // One tile step: softmax + PV of tile t from `sc`, S^T of tile t+1 into `sn` (for the last tile the ring slot is
-  // stale and `sn` is never used).
-  auto step = [&](int t, f32x16 (&sc)[2], f32x16 (&sn)[2]) {
-    if (t > 0) {  // K(t+1) and V(t) were issued one step ago
-      wait_vm0();
-      __syncthreads();
-    }
-    if (t + 2 < nt) issue_k(t + 2);
-    if (t + 1 < nt) issue_v(t + 1);
-    if (!active) return;
-    const f32x2 rh = f32x2{relh_q[2 * t], relh_q[2 * t + 1]};
-    // running max (the last PV k-step of the previous tile is still in the matrix pipe under this)
-    float mx0 = sc[0][0], mx1 = sc[1][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, sc[0][r]); mx1 = fmaxf(mx1, sc[1][r]); }
-    float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    if (__builtin_amdgcn_ballot_w64(mn > m)) {  // wave-uniform: skip the O rescale once the running max is stable
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
-      l *= alpha;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-      m = mn;
-    }
-    const float nb0 = (rh[0] - m) * c2, nb1 = (rh[1] - m) * c2;
-    const char* kn_l = kring + ((t + 1) % 3) * C::TILE;
-    const char* v_l = vring + (t & 1) * C::TILE;
-    sn[0] = rwv;
-    sn[1] = rwv;
-    float ps = 0.f;
-    Chunk pb[2];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NSL; ++i) {
-      // (1) operands of the MFMAs at the end of this slice
-      Chunk ka[NSC], va[NPC];
-#pragma unroll
-      for (int c = 0; c < NSC; ++c) {
-        const int idx = i * NSC + c, b = idx & 1, ks = idx >> 1;
-        ka[c] = lds_chunk<T>(kn_l, 32 * b + col, 2 * ks + h);
-      }
-      const int pk = i / WIN - 1, pj = i % WIN;  // PV k-step whose window covers this slice (i >= WIN), position in it
-      if (i >= WIN) {
-#pragma unroll
-        for (int c = 0; c < NPC; ++c) {
-          const int cc = pj * NPC + c, b = cc >> 1, db = cc & 1;
-          if constexpr (TR) va[c] = lds_tr_chunk(v_l, db, b, pk, lane);
-          else va[c] = lds_perm_chunk(v_l, 32 * db + col, b, pk, h, T());
-        }
-      }
-      // (2) exponentials of accumulator rows 2i, 2i + 1 of both blocks
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int r = 2 * i + rr;
-        const float p0 = __builtin_amdgcn_exp2f(fmaf(sc[0][r], c2, nb0));
-        const float p1 = __builtin_amdgcn_exp2f(fmaf(sc[1][r], c2, nb1));
-        sc[0][r] = p0;
-        sc[1][r] = p1;
-        ps += p0 + p1;
-      }
-      // (3) matrix work
-#pragma unroll
-      for (int c = 0; c < NSC; ++c) {
-        const int idx = i * NSC + c, b = idx & 1, ks = idx >> 1;
-        mma32(sn[b], ka[c], qf[ks]);
-      }
-      if (i >= WIN) {
-        if (pj == 0) { pb[0] = acc_chunk(sc[0], pk, T()); pb[1] = acc_chunk(sc[1], pk, T()); }
-#pragma unroll
-        for (int c = 0; c < NPC; ++c) {
-          const int cc = pj * NPC + c, b = cc >> 1, db = cc & 1;
-          mma32(o[db], va[c], pb[b]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    l += ps;
-    // last PV k-step: overlaps the next step's max update (same wave) and the partner wave
-    pb[0] = acc_chunk(sc[0], C::KS_B - 1, T());
-    pb[1] = acc_chunk(sc[1], C::KS_B - 1, T());
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        if constexpr (TR) mma32(o[db], lds_tr_chunk(v_l, db, b, C::KS_B - 1, lane), pb[b]);
-        else mma32(o[db], lds_perm_chunk(v_l, 32 * db + col, b, C::KS_B - 1, h, T()), pb[b]);
-      }
-  };
-
-  f32x16 sa[2], sb[2];
-  issue_k(0);
-  issue_v(0);
-  if (nt > 1) issue_k(1);
-  wait_vm0();
-  __syncthreads();
-  if (active) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      sa[b] = rwv;
-#pragma unroll
-      for (int ks = 0; ks < C::KS_D; ++ks) mma32(sa[b], lds_chunk<T>(kring, 32 * b + col, 2 * ks + h), qf[ks]);
-    }
-  }
-  for (int t = 0; t < nt; t += 2) {
-    step(t, sa, sb);
-    if (t + 1 < nt) step(t + 1, sb, sa);
-  }
-  l += __shfl_xor(l, 32, 64);
-  if (q0 + col < a.N) {
-    const float inv = 1.f / l;
-    T* orow = (T*)a.out + ((long)s * a.N + q) * a.ldo + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *(typename Traits<T>::Vec4*)(orow + 32 * db + 8 * i + 4 * h) =
-            pack4<T>(o[db][4 * i] * inv, o[db][4 * i + 1] * inv, o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
-    if (h == 0 && a.lse2) a.lse2[sh * npad + q] = m * c2 + log2f(l);
-  }
-}
-
 // ------------------------------------------------------------------------------------------- backward: dQ
 // Query-stationary, same swapped layout as forward.  Per key tile: S^T (bias as initial accumulator) ->
 // P^T = exp2(S^T c2 - lse2) -> dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.

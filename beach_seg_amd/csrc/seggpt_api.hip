@@ -262,17 +262,13 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.relhT = relh_s; a.out = attn_o;
       a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
       static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
-      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024),
-                           allow_lds(attn_fwd_sp_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_sp_kernel<T, can_tr>, 160 * 1024), true);
+      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024), true);
       (void)once2;
-      static const bool sp = getenv("BSG_ATTN_FWD_SP") != nullptr;  // hand-interleaved variant: measured 7 % slower, kept for A/B
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
       const dim3 agrid(((N + 127) / 128) * nh * S);
-      const int relh_lds = 4 * 32 * (hp | 1) * 4;  // per-wave relh tables (relh_stride)
-      const int lds = (sp ? 5 * AttnK<T>::TILE + relh_lds : std::max(4 * AttnK<T>::TILE, relh_lds)) + ldspad;  // plain kernel: prologue scratch aliases the tiles
-      if (sp && tr) hipLaunchKernelGGL((attn_fwd_sp_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
-      else if (sp) hipLaunchKernelGGL((attn_fwd_sp_kernel<T, false>), agrid, dim3(256), lds, st, a);
-      else if (tr) hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
+      const int relh_lds = 4 * 32 * (hp | 1) * 4;  // prologue scratch (32 x HS relh table per wave) aliases the tiles
+      const int lds = std::max(4 * AttnK<T>::TILE, relh_lds) + ldspad;
+      if (tr) hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
       else hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), lds, st, a);
       CHECK_LAUNCH();
     }
