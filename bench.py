@@ -60,9 +60,9 @@ def cpu_baseline(geometry, threads: int) -> dict:
 
 def gemm_hbm_traffic_per_launch() -> float | None:
     """HBM bytes per GEMM launch (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc
-    summary of this same command (`profiles/r1_step6_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
+    summary of this same command (`profiles/r1_step8_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
     passes cannot run inside the timed process, so the figure is measured offline and reported here."""
-    f = ROOT / "profiles" / "r1_step6_pmc_summary.json"
+    f = ROOT / "profiles" / "r1_step8_pmc_summary.json"
     if not f.exists():
         return None
     n = b = 0.0
