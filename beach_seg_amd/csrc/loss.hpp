@@ -182,8 +182,9 @@ __global__ void vote_paste_kernel(const uint8_t* __restrict__ masks, uint8_t* __
   if (sy >= ymax - ymin || sx >= xmax - xmin) return;
   const int y = ymin + sy, x = xmin + sx;
   if (y < 0 || y >= mh || x < 0 || x >= mw) return;
-  const int iy = min((int)floorf(sy * ((float)hin / crop)), hin - 1);
-  const int ix = min((int)floorf(sx * ((float)win / crop)), win - 1);
+  // cv2.resize(INTER_NEAREST) (src/predict.py:259): ifx = 1 / (dsize / (double)ssize); sx = min(cvFloor(x * ifx), ssize - 1), in double
+  const int iy = min((int)floor((double)sy * (1.0 / ((double)crop / (double)hin))), hin - 1);
+  const int ix = min((int)floor((double)sx * (1.0 / ((double)crop / (double)win))), win - 1);
   const int cls = masks[((long)ci * hin + iy) * win + ix];
   uint8_t* c = counter + ((long)y * mw + x) * K + cls;
   *c = (uint8_t)(*c + 1);  // crops of one launch must not overlap (callers launch overlapping crops separately)

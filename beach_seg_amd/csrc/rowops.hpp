@@ -127,10 +127,11 @@ __global__ void cast_rows_kernel(const float* x, T* y, long n4, float scale) {
 // mask_token there).  One thread per (row, c, i): 64 B in, 16 elements out.
 template <typename T>
 __global__ void patchify_kernel(const float* __restrict__ prompt_img, const float* __restrict__ query_img,
-                                const float* __restrict__ prompt_mask, T* __restrict__ A, int B, int hp, int wp) {
+                                const float* __restrict__ prompt_mask, T* __restrict__ A, int B, int hp, int wp, int split) {
   const int N = hp * wp, hh = hp / 2;
   const long total = (long)2 * B * N * 48;
   const int Hh = hh * 16, W = wp * 16;
+  const long lda = split ? 3 * 768 : 768;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int ci = idx % 48;
     const long m = idx / 48;
@@ -139,13 +140,37 @@ __global__ void patchify_kernel(const float* __restrict__ prompt_img, const floa
     const float* src = nullptr;
     if (s < B) src = (ph < hh ? prompt_img : query_img) + (((long)s * 3 + c) * Hh + (ph % hh) * 16 + i) * W + pw * 16;
     else if (ph < hh) src = prompt_mask + (((long)(s - B) * 3 + c) * Hh + ph * 16 + i) * W + pw * 16;
-    T* dst = A + m * 768 + c * 256 + i * 16;
+    T* dst = A + m * lda + c * 256 + i * 16;
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (src) v = *(const f32x4*)(src + 4 * j4);
-      *(typename Traits<T>::Vec4*)(dst + 4 * j4) = pack4<T>(v[0], v[1], v[2], v[3]);
+      const typename Traits<T>::Vec4 hi = pack4<T>(v[0], v[1], v[2], v[3]);
+      *(typename Traits<T>::Vec4*)(dst + 4 * j4) = hi;
+      if (split) {  // [hi | hi | lo]: with the weight laid out [W_hi | W_lo | W_hi] one K = 3*768 GEMM sums hi*W_hi + hi*W_lo + lo*W_hi
+        *(typename Traits<T>::Vec4*)(dst + 768 + 4 * j4) = hi;
+        *(typename Traits<T>::Vec4*)(dst + 1536 + 4 * j4) =
+            pack4<T>(v[0] - to_f32(hi[0]), v[1] - to_f32(hi[1]), v[2] - to_f32(hi[2]), v[3] - to_f32(hi[3]));
+      }
     }
+  }
+}
+
+// fp32 rows -> [hi | hi | lo] in T (3 * D columns): the A operand of a split-precision GEMM against [W_hi | W_lo | W_hi].
+// Row r of the output is physical input row (r / rpg) * gstride + r % rpg.
+template <typename T>
+__global__ void split_rows_kernel(const float* __restrict__ x, T* __restrict__ y, long rows, int D, int rpg, long gstride) {
+  const long n4 = rows * (D / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / (D / 4);
+    const int c = (int)(i % (D / 4)) * 4;
+    const f32x4 v = *(const f32x4*)(x + ((r / rpg) * gstride + r % rpg) * D + c);
+    const typename Traits<T>::Vec4 hi = pack4<T>(v[0], v[1], v[2], v[3]);
+    T* dst = y + r * 3 * D + c;
+    *(typename Traits<T>::Vec4*)dst = hi;
+    *(typename Traits<T>::Vec4*)(dst + D) = hi;
+    *(typename Traits<T>::Vec4*)(dst + 2 * D) =
+        pack4<T>(v[0] - to_f32(hi[0]), v[1] - to_f32(hi[1]), v[2] - to_f32(hi[2]), v[3] - to_f32(hi[3]));
   }
 }
 

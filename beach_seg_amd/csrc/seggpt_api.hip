@@ -78,7 +78,8 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
                mlp = m->c.mlp_dim, npad = m->npad, hp = m->hp, nt = m->c.num_taps;
   const size_t HW = (size_t)m->c.canvas_h * m->c.canvas_w;
   const size_t r2 = 2 * (size_t)B * N, r1 = (size_t)B * N;
-  p.add("patch_a", -1, r2 * 768 * es);
+  const size_t ek = m->c.embed_split ? 3 : 1;  // split-precision patch embed: K = 3 x 768 ([hi | hi | lo] x [W_hi | W_lo | W_hi])
+  p.add("patch_a", -1, r2 * 768 * ek * es);
   if (train) {
     for (size_t l = 0; l < L; ++l) {
       const size_t rows = (size_t)m->streams(l, B) * N, S = m->streams(l, B);
@@ -121,6 +122,7 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     p.add("delta", -1, (size_t)B * nh * npad * 4);
     p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
     p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
+    if (m->c.embed_split) p.add("dx_split", -1, (size_t)B * (N / 2) * 3 * D * es);
   }
   return p;
 }
@@ -218,14 +220,15 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   {
     const long total = (long)2 * B * N * 48;
     hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)std::min<long>((total + 255) / 256, 65535 * 16)), dim3(256), 0, st,
-                       prm, pix, pmask, patch_a, B, hp, wp);
+                       prm, pix, pmask, patch_a, B, hp, wp, m->c.embed_split);
     CHECK_LAUNCH();
   }
   float* pool[3] = {c.template at<float>("x_a"), c.template at<float>("x_b"), c.template at<float>("x_c")};
   float* x_cur = train ? c.template at<float>("x_in", 0) : pool[0];
   {
     GemmArgs g{};
-    g.A = patch_a; g.W = m->gw(0); g.M = 2 * B * N; g.N = D; g.K = 768; g.lda = 768;
+    const int ek = m->c.embed_split ? 3 : 1;
+    g.A = patch_a; g.W = m->gw(0); g.M = 2 * B * N; g.N = D; g.K = 768 * ek; g.lda = 768 * ek;
     g.tokens = N; g.batch = B; g.out = x_cur; g.ldo = D; g.aux = m->gw(emb == 0 ? 2 : 3); g.ldaux = D;
     gemm<T, A_PLAIN, EPI_EMBED>(m, g, st);
     CHECK_LAUNCH();
@@ -499,6 +502,14 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   {  // patch-embed dgrad over the prompt (top) half of the image canvas, un-patchified straight into the output
     GemmArgs g{};
     g.A = dx_t; g.W = m->gw(1); g.M = B * (N / 2); g.N = 768; g.K = D; g.lda = D; g.a_rpg = N / 2; g.a_gstride = N;
+    if (m->c.embed_split) {  // the last dgrad at split precision: fp32 dx -> [hi | hi | lo] against [W_hi | W_lo | W_hi]^T
+      T* dxs = c.template at<T>("dx_split");
+      const long rows_s = (long)B * (N / 2), n4 = rows_s * D / 4;
+      hipLaunchKernelGGL((split_rows_kernel<T>), dim3((unsigned)std::min<long>((n4 + 255) / 256, 65535)), dim3(256), 0, st, dx, dxs,
+                         rows_s, D, N / 2, (long)N);
+      CHECK_LAUNCH();
+      g.A = dxs; g.K = 3 * D; g.lda = 3 * D; g.a_rpg = 0; g.a_gstride = 0;
+    }
     g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W; g.out = gprompt;
     gemm<T, A_PLAIN, EPI_UNPATCH>(m, g, st);
     CHECK_LAUNCH();
@@ -527,6 +538,8 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   for (int i = 0; i < c.num_taps; ++i)
     if (c.taps[i] < c.merge_index || c.taps[i] >= c.num_layers) return fail("tap index %d out of range", c.taps[i]);
   if (c.merge_index < 0 || c.merge_index >= c.num_layers) return fail("merge_index out of range");
+  if (c.embed_split != 0 && c.embed_split != 1) return fail("embed_split must be 0 or 1");
+  if (c.embed_split && c.dtype == BSG_DTYPE_F32) return fail("embed_split applies to the bf16 dtype only");
   const int need = BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * c.num_layers;
   if (n_weights != need) return fail("weight table has %d entries, expected %d", n_weights, need);
   for (int i = 0; i < need; ++i) if (!weights[i]) return fail("weight table entry %d is null", i);
@@ -711,9 +724,11 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
   GemmArgs g{};
   g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.out = out; g.ldo = N;
   hipStream_t st = (hipStream_t)stream;
+#ifdef BSG_DIAG  // result-corrupting timing switches exist only in diagnostic builds (-DBSG_DIAG)
   static const bool nostore = getenv("BSG_GEMM_NOSTORE") != nullptr;
-  if (getenv("BSG_GEMM_LDO0")) g.ldo = 0;  // diagnostics: every row lands on row 0 (stores stay in L2)
+  if (getenv("BSG_GEMM_LDO0")) g.ldo = 0;  // every row lands on row 0 (stores stay in L2)
   if (nostore) { gemm<bf16_t, A_PLAIN, EPI_NONE>(&dummy, g, st); CHECK_LAUNCH(); return 0; }
+#endif
   if (dtype == BSG_DTYPE_F32) { if (bias) gemm<float, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<float, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
 #ifdef BSG_DIAG_STAMPS  // the diagnostic build times the GELU epilogue through the bias entry
   else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS_GELU>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }

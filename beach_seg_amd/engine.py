@@ -26,7 +26,22 @@ def reduce_prompt_grads(flat: torch.Tensor, process_group=None) -> None:
     """The ONE data-path collective of a training step: sum over ranks of [P x n gradient rows | P touched flags].
     `nccl` (= RCCL over xGMI) on GPUs; `gloo` in the CPU tests."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+        if flat.is_cuda and dist.get_backend(process_group) == "gloo":  # one-GPU rehearsal / tests: gloo moves host memory
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=process_group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+
+
+def broadcast_from_rank0(t: torch.Tensor, process_group=None) -> None:
+    """Rank 0's copy of `t` to every rank (gloo needs host memory: staged through the CPU there)."""
+    if dist.get_backend(process_group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=0, group=process_group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=0, group=process_group)
 
 
 def shard_batch(global_batch: int, rank: int, world: int) -> range:
@@ -55,6 +70,8 @@ class PromptTrainEngine:
         self.loss_beta, self.loss_variant = loss_beta, loss_variant
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:  # replicas must start from the same parameters, as DDP guarantees at construction
+            broadcast_from_rank0(self.params, process_group)
         n = self.params[0].numel()
         self._flat = torch.zeros(P * n + P, dtype=torch.float32, device=dev)
         self.grads = self._flat[: P * n].view_as(self.params)

@@ -15,25 +15,73 @@ from .model import PromptModel
 
 
 class Accumulator:
-    def __init__(self, out_shape: tuple[int, int], classes: tuple[str, ...], device):
+    """Device-side vote mosaic with the life cycle of the reference class (`src/predict.py:55-159`): a change of date
+    finalises the previous mosaic first (`save_current`, `:129-132`), and leaving the `with` block finalises the last
+    one (`__exit__`, `:90-91`).  "Finalise" here = arg-max over the votes (`:100`) handed to `on_finish(date, mosaic)`
+    and kept in `finished`; the PNG / GeoTIFF export of `:93-112` is the caller's (out of scope)."""
+
+    def __init__(self, out_shape: tuple[int, int], classes: tuple[str, ...], device, on_finish=None):
         self.out_shape, self.num_classes, self.classes, self.device = out_shape, len(classes), classes, device
         self.current_date = None
         self.current_pred_counter = None
+        self.on_finish = on_finish
+        self.finished: list[tuple[str, torch.Tensor]] = []
+
+    def __enter__(self):
+        assert self.current_pred_counter is None and self.current_date is None
+        return self
+
+    def __exit__(self, a, b, c):
+        self.save_current()
+
+    def save_current(self) -> torch.Tensor:
+        assert self.current_pred_counter is not None and self.current_date is not None
+        pred = ops.vote_argmax(self.current_pred_counter)
+        self.finished.append((self.current_date, pred))
+        if self.on_finish is not None:
+            self.on_finish(self.current_date, pred)
+        return pred
 
     def initialize_current(self, date: str) -> None:
         self.current_date = date
         self.current_pred_counter = torch.zeros((*self.out_shape, self.num_classes), dtype=torch.uint8, device=self.device)
 
-    def update(self, date: str, crops: torch.Tensor, masks: torch.Tensor, crop_size: int) -> None:
-        """crops i32 (n,4) (xmin,ymin,xmax,ymax); masks u8 (n,hin,win) decoded at network resolution."""
+    def update(self, date: str, crops: torch.Tensor, masks: torch.Tensor, crop_size: int,
+               disjoint: bool = False) -> None:
+        """crops i32 (n,4) (xmin,ymin,xmax,ymax); masks u8 (n,hin,win) decoded at network resolution.  `disjoint`:
+        the caller guarantees that the windows of this call do not overlap each other (a regular grid with stride >=
+        crop size): one launch, no host round trip.  Otherwise the windows are grouped on the host once per call."""
         if date != self.current_date:
+            if self.current_pred_counter is not None:
+                self.save_current()
             self.initialize_current(date)
+        if disjoint:
+            ops.vote_paste(self.current_pred_counter, masks, crops.to(self.device), crop_size)
+            return
         # votes are plain uint8 read-modify-writes: windows that overlap go in separate launches
         for group in _non_overlapping_groups(crops):
             ops.vote_paste(self.current_pred_counter, masks[group], crops[group].to(self.device), crop_size)
 
     def result(self) -> torch.Tensor:
         return ops.vote_argmax(self.current_pred_counter)
+
+
+def crops_are_disjoint(crops: torch.Tensor) -> bool:
+    """True when no two windows of the (n,4) list overlap: decided ONCE per mosaic on the host (sort by the grid
+    origin; a regular grid with stride >= window side is disjoint by construction)."""
+    b = crops.cpu().numpy().astype("int64")
+    if len(b) < 2:
+        return True
+    w, h = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    if (w != w[0]).any() or (h != h[0]).any():
+        return len(_non_overlapping_groups(crops)) == 1
+    # equal-size windows: they are disjoint iff all distinct origin pairs differ by >= the side in x or in y
+    import numpy as np
+    xs, ys = np.unique(b[:, 0]), np.unique(b[:, 1])
+    on_lattice = len(b) == len(np.unique(b[:, :2], axis=0))
+    if on_lattice and (len(xs) < 2 or np.diff(xs).min() >= w[0]) and (len(ys) < 2 or np.diff(ys).min() >= h[0]):
+        return True
+    return len(_non_overlapping_groups(crops)) == 1
 
 
 def _non_overlapping_groups(crops: torch.Tensor) -> list[torch.Tensor]:
@@ -57,6 +105,8 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
     Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`).
     `use_graph`: replay the network forward from one captured hipGraph (full batches only; the tail runs eagerly)."""
     acc = Accumulator(out_shape, model.conf.classes, model.device)
+    disjoint = crops_are_disjoint(crops)  # decided once per mosaic: no host round trip per batch of windows
+    crops_dev = crops.to(model.device)
     graphed = model.model.capture_forward(batch_size) if use_graph and images.shape[0] >= batch_size else None
     for s in range(0, images.shape[0], batch_size):
         sl = slice(s, s + batch_size)
@@ -68,7 +118,7 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
             pred = model.process_pred_masks(out, pal_norm)
         else:
             pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
-        acc.update(date, crops[sl], pred.to(torch.uint8), crop_size)
+        acc.update(date, crops_dev[sl] if disjoint else crops[sl], pred.to(torch.uint8), crop_size, disjoint=disjoint)
     return acc.result()
 
 

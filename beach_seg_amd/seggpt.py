@@ -76,7 +76,16 @@ def _rel_cat(rel_h: torch.Tensor, rel_w: torch.Tensor) -> torch.Tensor:
     return cat
 
 
-def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) -> list[torch.Tensor]:
+def _split3(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[W_hi | W_lo | W_hi] along the contraction axis (W = hi + lo in `dtype`): partner of activations laid out
+    [x_hi | x_hi | x_lo], so ONE low-precision GEMM with K tripled sums x_hi W_hi + x_hi W_lo + x_lo W_hi."""
+    w = w.float()
+    hi = w.to(dtype)
+    lo = (w - hi.float()).to(dtype)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, embed_split: bool = False) -> list[torch.Tensor]:
     """Device tensors in the slot order documented in `include/beach_seg_amd.h`."""
     missing = [k for k in state_dict_shapes(g) if k not in sd]
     if missing:
@@ -102,8 +111,10 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) 
     conv_w = cw.permute(0, 2, 3, 1).reshape(64, 9, 64)  # [co][tap][ci]
     conv_wT = cw.flip(2, 3).permute(1, 2, 3, 0).reshape(64, 9, 64)  # [ci][tap'][co], taps flipped (dgrad)
     dw, dwT = lin("decoder.decoder_embed.weight")
+    pw32 = pw.detach().to(device=device, dtype=torch.float32)
+    patch = (_split3(pw32, dtype), _split3(pw32.t(), dtype)) if embed_split else (T(pw), T(pw.t()))
     table = [
-        T(pw), T(pw.t()), f32(tab_i), f32(tab_s),
+        patch[0], patch[1], f32(tab_i), f32(tab_s),
         f32(sd["model.encoder.layernorm.weight"]), f32(sd["model.encoder.layernorm.bias"]),
         dw, dwT, f32(sd["decoder.decoder_embed.bias"]), T(conv_w), T(conv_wT),
         f32(sd["decoder.decoder_pred.conv.bias"]), f32(sd["decoder.decoder_pred.layernorm.weight"]),
@@ -129,24 +140,48 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device) 
     return table
 
 
+class _WsLease:
+    """Exclusive hold of one saved-activation workspace by one autograd node: taken at forward, given back when the
+    node (its `ctx`) is freed.  A second grad-enabled forward while the first graph is alive therefore gets a
+    workspace of its own (f1, f2, b1, b2 works like it does through the HF module's autograd), and a backward
+    can never read activations of another forward."""
+
+    def __init__(self, model: "SegGptNative", ws: torch.Tensor):
+        self.model, self.ws = model, ws
+        model._leased.add(ws.data_ptr())
+
+    def __del__(self):
+        try:
+            self.model._leased.discard(self.ws.data_ptr())
+        except Exception:  # interpreter shutdown
+            pass
+
+
 class _SegGptFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: "SegGptNative", pixel_values, prompt_pixel_values, prompt_masks, emb: int, need_grad: bool):
+        ws = model._free_train_workspace(pixel_values.shape[0]) if need_grad else None
         pred = model._run_forward(pixel_values.detach(), prompt_pixel_values.detach(), prompt_masks.detach(), emb,
-                                  train=need_grad)
+                                  train=need_grad, ws=ws)
         ctx.model, ctx.batch = model, pixel_values.shape[0]
+        ctx.lease = _WsLease(model, ws) if need_grad else None
         return pred
 
     @staticmethod
     def backward(ctx, grad_pred):
-        g = ctx.model._run_backward(grad_pred.contiguous().float(), ctx.batch)
+        if ctx.lease is None:
+            raise RuntimeError("backward through a forward that saved no activations")
+        g = ctx.model._run_backward(grad_pred.contiguous().float(), ctx.batch, ws=ctx.lease.ws)
         return None, None, g, None, None, None
 
 
 class SegGptNative(torch.nn.Module):
     """Frozen SegGPT on the HIP kernels.  `dtype`: torch.float32 (parity mode) or torch.bfloat16."""
 
-    def __init__(self, state_dict: dict, geometry: SegGptGeometry, device="cuda:0", dtype=torch.bfloat16):
+    def __init__(self, state_dict: dict, geometry: SegGptGeometry, device="cuda:0", dtype=torch.bfloat16,
+                 embed_split: Optional[bool] = None):
+        """`embed_split` (16-bit dtypes; default on): patch embedding and its dgrad as split-precision GEMMs, so pixels and
+        the prompt-pixel gradient are not quantised to the MFMA operand type (`bsg_config.embed_split`)."""
         super().__init__()
         geometry.validate()
         if dtype not in (torch.float32, torch.bfloat16):
@@ -154,7 +189,10 @@ class SegGptNative(torch.nn.Module):
         self.geometry, self.dtype = geometry, dtype
         self._device = torch.device(device)
         self._lib = N.load()
-        self._table = build_weight_table(state_dict, geometry, dtype, self._device)
+        self.embed_split = (dtype != torch.float32) if embed_split is None else bool(embed_split)
+        if self.embed_split and dtype == torch.float32:
+            raise ValueError("embed_split applies to the 16-bit dtypes only")
+        self._table = build_weight_table(state_dict, geometry, dtype, self._device, self.embed_split)
         cfg = N.BsgConfig()
         g = geometry
         cfg.hidden_size, cfg.num_layers, cfg.num_heads = g.hidden_size, g.num_hidden_layers, g.num_attention_heads
@@ -165,12 +203,15 @@ class SegGptNative(torch.nn.Module):
             cfg.taps[i] = t
         cfg.layer_norm_eps = g.layer_norm_eps
         cfg.dtype = N.BSG_DTYPE_F32 if dtype == torch.float32 else N.BSG_DTYPE_BF16
+        cfg.embed_split = int(self.embed_split)
         ptrs = (C.c_void_p * len(self._table))(*[t.data_ptr() for t in self._table])
         h = C.c_void_p()
         with torch.cuda.device(self._device):
             N.check(self._lib.bsg_create(C.byref(cfg), ptrs, len(self._table), C.byref(h)))
         self._h = h
         self._ws: dict[tuple[int, int], torch.Tensor] = {}
+        self._train_ws: dict[int, list[torch.Tensor]] = {}  # per batch size: saved-activation workspaces
+        self._leased: set[int] = set()                      # data_ptrs held by live autograd nodes (_WsLease)
         self._last_ws: Optional[torch.Tensor] = None
 
     def __del__(self):
@@ -198,7 +239,21 @@ class SegGptNative(torch.nn.Module):
         if key not in self._ws:
             n = self._lib.bsg_workspace_bytes(self._h, batch, int(train))
             self._ws[key] = torch.zeros(n, dtype=torch.uint8, device=self._device)  # ABI: zero-initialised
+            if train:
+                self._train_ws.setdefault(batch, []).append(self._ws[key])
         return self._ws[key]
+
+    def _free_train_workspace(self, batch: int) -> torch.Tensor:
+        """A saved-activation workspace no live autograd node holds (the cached one first; a new one only when two
+        grad-enabled forwards of this batch size are alive at once)."""
+        self.workspace(batch, True)
+        for ws in self._train_ws[batch]:
+            if ws.data_ptr() not in self._leased:
+                return ws
+        n = self._lib.bsg_workspace_bytes(self._h, batch, 1)
+        ws = torch.zeros(n, dtype=torch.uint8, device=self._device)
+        self._train_ws[batch].append(ws)
+        return ws
 
     def workspace_region(self, batch: int, train: bool, name: str, layer: int = -1) -> torch.Tensor:
         """uint8 view of a named region of the most recent workspace of that shape (test / debugging aid)."""
@@ -221,12 +276,16 @@ class SegGptNative(torch.nn.Module):
             out[name] = (ms.value, fl.value, n.value)
         return out
 
-    def _run_forward(self, pix, prm, pmask, emb: int, train: bool, ensemble: bool = False) -> torch.Tensor:
+    def _run_forward(self, pix, prm, pmask, emb: int, train: bool, ensemble: bool = False,
+                     ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`ws` None: the fused-engine convention -- a free workspace of this shape, remembered as `_last_ws` for the
+        `_run_backward` that follows immediately (no autograd node involved)."""
         B = pix.shape[0]
         H, W = self.geometry.image_size
         pix, prm, pmask = (t.to(self._device, torch.float32).contiguous() for t in (pix, prm, pmask))
         pred = torch.empty((B, 3, H, W), dtype=torch.float32, device=self._device)
-        ws = self.workspace(B, train)
+        if ws is None:
+            ws = self._free_train_workspace(B) if train else self.workspace(B, False)
         with torch.cuda.device(self._device):
             if ensemble:
                 N.check(self._lib.bsg_forward_ensemble(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb,
@@ -237,13 +296,18 @@ class SegGptNative(torch.nn.Module):
         self._last_ws = ws if train else None
         return pred
 
-    def _run_backward(self, grad_pred: torch.Tensor, B: int, first_row: int = 0) -> torch.Tensor:
-        """`first_row` > 0: the caller guarantees grad_pred == 0 on canvas rows < first_row (bsg_backward_rows)."""
-        if self._last_ws is None:
+    def _run_backward(self, grad_pred: torch.Tensor, B: int, first_row: int = 0,
+                      ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`first_row` > 0: the caller guarantees grad_pred == 0 on canvas rows < first_row (bsg_backward_rows).
+        `ws`: the workspace the matching forward saved into (autograd path); None = the engine's last forward."""
+        if ws is None:
+            ws = self._last_ws
+        if ws is None:
             raise RuntimeError("backward without a forward that saved activations")
+        if ws.numel() < self._lib.bsg_workspace_bytes(self._h, B, 1):
+            raise RuntimeError(f"backward with batch {B} on a workspace saved by a smaller forward")
         H, W = self.geometry.image_size
         g = torch.empty((B, 3, H // 2, W), dtype=torch.float32, device=self._device)
-        ws = self._last_ws
         with torch.cuda.device(self._device):
             N.check(self._lib.bsg_backward_rows(self._h, _stream(), B, _ptr(grad_pred), int(first_row), _ptr(g), _ptr(ws),
                                                 ws.numel()))

@@ -13,9 +13,12 @@ HBM before the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line with `roofline` (GEMM kernels: algorithmic flops / HIP-event kernel time, measured
-live on the launch stream during the timed steps) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host
-cores on one tile of the same geometry).
+The K timed steps run with the library's per-launch event profiling OFF.  Rank 0 then runs a few extra PROFILED
+steps (HIP events on the launch stream around every GEMM / attention / conv launch) for `roofline` and the
+per-kernel table, and at N=1 also measures: `fwd_ms_per_tile` (the second half of BASELINE.json's metric: inference
+forward, batch 64, replayed from one hipGraph), `f32_parity_mode_tiles_per_s` (the same train step in the exact-f32
+MFMA mode that meets north_star's 1e-3 tolerance) and `cpu_baseline` (the CPU oracle on the host cores, BASELINE.md
+section 3: B=2, one warm-up + three timed steps).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -33,9 +36,20 @@ TRAIN_FLOPS_PER_TILE = 3.2681e12  # forward 1589.7 GF + 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(geometry, threads: int) -> dict:
-    """The oracle (CPU restatement of the reference arithmetic, fp32 eager torch) on ONE synthetic tile:
-    forward + reference loss + backward to the prompt pixels.  ~10-30 s of host work."""
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(geometry, threads: int, batch: int = 2, warmup: int = 1, timed: int = 3) -> dict:
+    """the oracle (CPU restatement of the reference arithmetic, fp32 eager torch) on BASELINE
+    config 1's shape -- B=2 synthetic tiles of the full geometry, forward + reference loss + backward to the prompt
+    pixels -- one warm-up step, then `timed` steps on all host threads this process may use."""
     import torch
 
     from beach_seg_amd.weights import synth_state_dict
@@ -44,33 +58,64 @@ def cpu_baseline(geometry, threads: int) -> dict:
 
     torch.set_num_threads(threads)
     sd = synth_state_dict(geometry, seed=0)
-    pix, prm, pm_cls, lb_cls, pal = synth_inputs(geometry, 1, 7)
+    pix, prm, pm_cls, lb_cls, pal = synth_inputs(geometry, batch, 7)
     pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
     lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
-    p = prm.clone().requires_grad_(True)
-    t0 = time.perf_counter()
-    pred = O.forward(sd, geometry, pix, p, pm, labels=lab)
-    loss = O.seggpt_loss(pred, lab, (lb_cls != 0)[:, None], 0.01, "reference")
-    torch.autograd.grad(loss, p)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": "1 tile (B=1), one fwd + SegGptLoss + bwd step of the ViT-L oracle, fp32 eager torch, "
-                      f"{dt:.1f} s, no warm-up"}
+
+    def one():
+        p = prm.clone().requires_grad_(True)
+        pred = O.forward(sd, geometry, pix, p, pm, labels=lab)
+        loss = O.seggpt_loss(pred, lab, (lb_cls != 0)[:, None], 0.01, "reference")
+        torch.autograd.grad(loss, p)
+
+    for _ in range(warmup):
+        one()
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+        log(f"  cpu oracle step: {ts[-1]:.1f} s")
+    dt = sum(ts) / len(ts)
+    return {"value": round(batch / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model_name(),
+            "sample": f"B={batch} tiles of the full ViT-L geometry, fwd + SegGptLoss(reference) + bwd to the prompt pixels, "
+                      f"CPU oracle fp32 eager torch, {warmup} warm-up + {timed} timed steps, mean {dt:.1f} s/step "
+                      f"(min {min(ts):.1f}, max {max(ts):.1f})"}
 
 
-def gemm_hbm_traffic_per_launch() -> float | None:
+def csrc_sha() -> str:
+    """Hash of the kernel sources: ties a committed PMC summary to the kernels it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "beach_seg_amd" / "csrc").glob("*")):
+        if f.suffix in (".hpp", ".hip"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+PMC_SUMMARY = ROOT / "profiles" / "r2_pmc_summary.json"
+
+
+def gemm_hbm_traffic_per_launch() -> tuple[float | None, str]:
     """HBM bytes per GEMM launch (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc
-    summary of this same command (`profiles/r1_step8_pmc_summary.json`, produced by `tools/pmc_summary.py`): PMC
-    passes cannot run inside the timed process, so the figure is measured offline and reported here."""
-    f = ROOT / "profiles" / "r1_step8_pmc_summary.json"
-    if not f.exists():
-        return None
+    summary of this same command (`tools/pmc_summary.py`): PMC passes cannot run inside the timed process, so the
+    figure is measured offline.  The summary records the hash of the kernel sources it was taken on; if the kernels
+    have changed since, the figure is stale and None is reported."""
+    if not PMC_SUMMARY.exists():
+        return None, "no PMC summary committed"
+    d = json.loads(PMC_SUMMARY.read_text())
+    meta = d.get("_meta", {})
+    if meta.get("csrc_sha") != csrc_sha():
+        return None, f"PMC summary {PMC_SUMMARY.name} was taken on kernels {meta.get('csrc_sha')}, current {csrc_sha()}: stale"
     n = b = 0.0
-    for k, v in json.loads(f.read_text()).items():
+    for k, v in d.items():
         if "gemm_nt_kernel" in k:
             n += v["launches"]
             b += v["launches"] * (v["hbm_fetch_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6
-    return round(b / n) if n else None
+    return (round(b / n) if n else None), f"{PMC_SUMMARY.name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, offline pass, kernels {meta.get('csrc_sha')})"
 
 
 def log(msg: str) -> None:
@@ -96,6 +141,8 @@ def main() -> None:
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--geometry", default="vit_large")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip fwd_ms_per_tile / f32 parity mode / profiled steps")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra profiled steps after the timed region")
     ap.add_argument("--loss-variant", default="reference", choices=["reference", "per_sample"])
     args = ap.parse_args()
 
@@ -133,12 +180,13 @@ def main() -> None:
     log("model ready")
     B, P = args.batch, args.prompts
     Hh, W = g.image_size[0] // 2, g.image_size[1]
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
+    gen = torch.Generator(device=dev).manual_seed(7 + rank)  # per-rank DATA
     rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
     pix, label_color, prompt_mask_color = rn(B, 3, Hh, W), rn(B, 3, Hh, W), rn(B, 3, Hh, W)
     yes = torch.ones(B, 1, Hh, W, dtype=torch.bool, device=dev)
-    engine = PromptTrainEngine(model, torch.rand(P, 3, Hh, W, device=dev, generator=gen), lr=1e-3,
-                               loss_variant=args.loss_variant)
+    pgen = torch.Generator(device=dev).manual_seed(1007)  # the trainable prompts start IDENTICAL on every rank
+    engine = PromptTrainEngine(model, torch.rand(P, 3, Hh, W, device=dev, generator=pgen), lr=1e-3,
+                               loss_variant=args.loss_variant)  # (and the engine broadcasts rank 0's copy)
     idx = (torch.arange(B, device=dev) + rank * B) % P
 
     def step():
@@ -153,26 +201,35 @@ def main() -> None:
         step()
     fence()
     log("warm-up done")
-    model.profile(True)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # ---- timed region: exactly K steps, event profiling OFF
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    prof = model.profile_read()
-    model.profile(False)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
-    if not torch.isfinite(loss) and not os.environ.get("BSG_DIAG_ALLOW_NONFINITE"):  # timing-only ablation builds only
+    if not torch.isfinite(loss):
         raise SystemExit("non-finite loss")
+
+    # ---- extra PROFILED steps (outside the timed region; every rank steps, the step holds a collective at N > 1):
+    #      HIP events around every GEMM / attention / conv launch of rank 0
+    prof, nprof, tprof = None, max(1, args.profile_steps), 0.0
+    if not args.no_extras:
+        model.profile(rank == 0)
+        tp0 = time.perf_counter()
+        for _ in range(nprof):
+            step()
+        fence()
+        tprof = (time.perf_counter() - tp0) / nprof
+        if rank == 0:
+            prof = model.profile_read()
+        model.profile(False)
 
     if rank == 0:
         tiles = B * world * args.steps
-        ms, fl, n = prof["gemm"]
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
         out = {
             "metric": "train tiles/sec", "value": round(tiles / dt, 3), "unit": "tiles/s", "n_gpus": world,
@@ -186,17 +243,61 @@ def main() -> None:
                        "train_flops_per_tile": TRAIN_FLOPS_PER_TILE},
             "whole_step_tflops_per_gpu": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12, 1),
             "whole_step_frac_of_mfma_peak": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12 / peak, 4),
-            "roofline": {"kernel": "gemm_nt_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 1),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": gemm_hbm_traffic_per_launch() if args.batch == 64 and args.dtype == "bf16" else None,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, offline pass)",
-                         "avg_launch_ms": round(ms / max(n, 1), 4), "launches": n,
-                         "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2)},
-            "kernel_time_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
-            "kernel_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0 for k, v in prof.items()},
         }
+        if prof is not None:
+            ms, fl, n = prof["gemm"]
+            achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic, traffic_src = gemm_hbm_traffic_per_launch() if (args.batch == 64 and args.dtype == "bf16") else (None, "n/a")
+            out["roofline"] = {
+                "kernel": "gemm_nt_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": round(ms / max(n, 1), 4), "launches_per_step": n // nprof,
+                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 2),
+                "measured": f"HIP events on the launch stream over {nprof} extra profiled steps after the timed region "
+                            f"({tprof * 1e3:.1f} ms/step with the events on)"}
+            out["kernel_time_ms_per_step"] = {k: round(v[0] / nprof, 3) for k, v in prof.items()}
+            out["kernel_tflops"] = {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0 for k, v in prof.items()}
+        if world == 1 and not args.no_extras:
+            # ---- second half of BASELINE.json's metric: inference forward, batch B, one hipGraph (configs[3] inner loop)
+            graphed = model.capture_forward(B)
+            for _ in range(2):
+                graphed(pix, pix, prompt_mask_color)
+            torch.cuda.synchronize()
+            nrep = 10
+            tf0 = time.perf_counter()
+            for _ in range(nrep):
+                graphed(pix, pix, prompt_mask_color)
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - tf0) / nrep
+            out["fwd_ms_per_tile"] = round(tf * 1e3 / B, 4)
+            out["fwd"] = {"batch": B, "ms_per_batch": round(tf * 1e3, 2), "tiles_per_s": round(B / tf, 1), "hipgraph": True,
+                          "tflops": round(B / tf * 1.5897, 1), "reps": nrep}
+            log(f"inference forward (hipGraph, B={B}): {tf * 1e3:.1f} ms = {tf * 1e3 / B:.3f} ms/tile")
+            del graphed
+        if world == 1 and not args.no_extras and args.dtype == "bf16" and args.geometry == "vit_large":
+            # ---- the same train step in the f32 parity mode (exact-f32 MFMA: the mode that meets 1e-3 / bit-exact masks)
+            del engine, model
+            torch.cuda.empty_cache()
+            Bf = 16
+            mf = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=torch.float32)
+            ef = PromptTrainEngine(mf, torch.rand(P, 3, Hh, W, device=dev, generator=pgen), lr=1e-3, loss_variant=args.loss_variant)
+            fstep = lambda: ef.step(pix[:Bf], label_color[:Bf], yes[:Bf], idx[:Bf], prompt_mask_color[:Bf])
+            fstep()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                lf = fstep()
+            torch.cuda.synchronize()
+            tf32 = (time.perf_counter() - t1) / 2
+            out["f32_parity_mode_tiles_per_s"] = round(Bf / tf32, 2)
+            out["f32_parity_mode"] = {"batch": Bf, "ms_per_step": round(tf32 * 1e3, 1), "steps": 2, "warmup": 1,
+                                      "tflops": round(Bf / tf32 * TRAIN_FLOPS_PER_TILE / 1e12, 1), "peak_tflops": 157.3,
+                                      "loss_finite": bool(torch.isfinite(lf))}
+            log(f"f32 parity mode: {tf32 * 1e3:.0f} ms/step at B={Bf} = {Bf / tf32:.1f} tiles/s")
+            del ef, mf
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            log("timing the CPU oracle (one tile) ...")
+            log("timing the CPU oracle (B=2, 1 warm-up + 3 timed steps) ...")
             out["cpu_baseline"] = cpu_baseline(g, host_threads())
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -38,13 +38,17 @@ typedef struct bsg_config {
   int taps[BSG_MAX_TAPS]; /* intermediate_hidden_state_indices */
   float layer_norm_eps;
   int dtype;
+  int embed_split; /* bf16 only: 1 = the patch embedding (HF:108) and its dgrad run as split-precision GEMMs, K tripled:
+                      activations [hi | hi | lo] against weights [W_hi | W_lo | W_hi] (x = hi + lo in bf16), so the input
+                      pixels and the prompt-pixel gradient are not quantised to 8 bits; weight slots 0 / 1 then hold
+                      T[D][3*768] / T[768][3*D].  0.6 % of the FLOPs. */
 } bsg_config;
 
 typedef struct bsg_model bsg_model;
 
 /* Weight table (device pointers, caller-owned, must outlive the handle).  "T" = activation dtype of the
  * config; "wT" = the same Linear weight transposed ([in][out]) for the dgrad GEMMs.
- * global: 0 patch_w T[D][768]   1 patch_wT T[768][D]   2 tok_table_instance f32[2][N][D]
+ * global: 0 patch_w T[D][768]   1 patch_wT T[768][D] (embed_split: see bsg_config)   2 tok_table_instance f32[2][N][D]
  *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*64][taps*D]
  *         7 dec_wT T[taps*D][256*64]   8 dec_b f32   9 conv_w T[64 co][9][64 ci]   10 conv_wT T[64 ci][9][64 co]
  *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][64]   15 head_b f32[3]

@@ -8,11 +8,13 @@ import numpy as np
 
 
 def nearest_resize(mask: np.ndarray, size: int) -> np.ndarray:
-    """`cv2.resize(pred, (size, size), interpolation=cv2.INTER_NEAREST)` (`src/predict.py:259`):
-    source index = min(floor(dst * src/dst_size), src - 1) on both axes."""
+    """`cv2.resize(pred, (size, size), interpolation=cv2.INTER_NEAREST)` (`src/predict.py:259`), OpenCV's
+    resizeNN index rule in double precision: fx = dsize / (double) ssize, ifx = 1 / fx, source index =
+    min(cvFloor(dst * ifx), ssize - 1) on both axes.  cv2 is not importable here ("parity unpinned" beyond this
+    restatement of imgproc/resize.cpp); for dyadic ratios (448 -> 112) every formulation agrees."""
     h, w = mask.shape
-    ys = np.minimum(np.floor(np.arange(size) * (h / size)).astype(np.int64), h - 1)
-    xs = np.minimum(np.floor(np.arange(size) * (w / size)).astype(np.int64), w - 1)
+    ys = np.minimum(np.floor(np.arange(size, dtype=np.float64) * (1.0 / (np.float64(size) / np.float64(h)))).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(size, dtype=np.float64) * (1.0 / (np.float64(size) / np.float64(w)))).astype(np.int64), w - 1)
     return mask[ys[:, None], xs[None, :]]
 
 

@@ -96,6 +96,29 @@ def test_validation_forward_and_predict_mosaic():
     assert torch.isfinite(l) and int(pm.val_metrics.state().sum()) > 0
 
 
+def test_accumulator_finalises_the_previous_date():
+    """`Accumulator.update` on a new date first saves the mosaic of the previous one (`src/predict.py:129-132`), and
+    leaving the `with` block saves the last (`:90-91`)."""
+    from beach_seg_amd.predict import Accumulator
+
+    g = torch.Generator().manual_seed(4)
+    masks = torch.randint(0, 4, (4, 32, 32), generator=g, dtype=torch.uint8).to(DEV)
+    crops = torch.tensor([[0, 0, 16, 16], [16, 0, 32, 16], [8, 8, 24, 24], [0, 16, 16, 32]], dtype=torch.int32)
+    seen = []
+    with Accumulator((32, 32), ("nodata", "sand", "water", "veg"), DEV, on_finish=lambda d, m: seen.append(d)) as acc:
+        acc.update("2020-01-01", crops[:2], masks[:2], 16, disjoint=True)
+        acc.update("2020-01-01", crops[2:3], masks[2:3], 16)
+        acc.update("2020-02-01", crops[3:], masks[3:], 16)
+    assert seen == ["2020-01-01", "2020-02-01"] and [d for d, _ in acc.finished] == seen
+    for date, sl in (("2020-01-01", slice(0, 3)), ("2020-02-01", slice(3, 4))):
+        counter = np.zeros((32, 32, 4), np.uint8)
+        for j in range(sl.start, sl.stop):
+            PO.accumulate(counter, tuple(int(v) for v in crops[j]),
+                          PO.one_hot(PO.nearest_resize(masks[j].cpu().numpy().astype(np.int64), 16), 4))
+        got = dict(acc.finished)[date]
+        assert np.array_equal(got.cpu().numpy(), PO.vote_argmax(counter).astype(np.uint8))
+
+
 def test_hipgraph_replay_equals_eager_forward():
     """BASELINE config 4: the forward is capturable (no allocation / synchronisation inside the C ABI) and a graph
     replay reproduces the eager launch sequence bit for bit."""

@@ -158,6 +158,52 @@ def test_errors_match_the_hf_contract():
         model(pixel_values=bad, prompt_pixel_values=x, prompt_masks=x)
 
 
+def test_two_live_forwards_then_two_backwards():
+    """f1, f2, b1, b2 through the autograd boundary (two losses alive at once, different batch sizes): every backward
+    must use the activations of ITS forward, as autograd through the HF module does."""
+    g = SegGptGeometry.tiny()
+    sd = synth_state_dict(g, seed=1)
+    model = model_for("tiny", 1, torch.float32)
+
+    def case(B, seed):
+        pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, seed)
+        pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
+        lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
+        return pix, prm, pm, lab, (lb_cls != 0)[:, None]
+
+    cases = [case(2, 21), case(3, 22), case(2, 23)]
+    refs = []
+    for pix, prm, pm, lab, yes in cases:
+        p = prm.clone().requires_grad_(True)
+        loss = O.seggpt_loss(O.forward(sd, g, pix, p, pm), lab, yes, 0.01, "reference")
+        refs.append(torch.autograd.grad(loss, p)[0])
+    ps, losses = [], []
+    for pix, prm, pm, lab, yes in cases:  # three forwards alive together (two share a batch size)
+        p = prm.to(DEV).requires_grad_(True)
+        out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
+        losses.append(ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference"))
+        ps.append(p)
+    assert len(model._leased) == 3
+    for i in (0, 1, 2):
+        losses[i].backward()
+    for p, ref in zip(ps, refs):
+        assert relmax(p.grad, ref) < 1e-4
+    with torch.no_grad():  # an inference forward in between does not disturb a pending backward
+        pix, prm, pm, lab, yes = cases[0]
+        p = prm.to(DEV).requires_grad_(True)
+        out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
+    p = prm.to(DEV).requires_grad_(True)
+    out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
+    with torch.no_grad():
+        model(pixel_values=pix.to(DEV), prompt_pixel_values=prm.to(DEV), prompt_masks=pm.to(DEV))
+    ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference").backward()
+    assert relmax(p.grad, refs[0]) < 1e-4
+    del ps, losses, out, p
+    import gc
+    gc.collect()
+    assert len(model._leased) == 0  # every workspace is given back once its graph is gone
+
+
 # ------------------------------------------------------------------------------------ wrapper arithmetic
 def test_loss_both_variants_vs_reference(golden_dir):
     rec = np.load(golden_dir / "wrapper.npz")
@@ -241,6 +287,14 @@ def test_predict_vote_glue_bit_exact(golden_dir):
     want = np.zeros((112, 112, 4), np.uint8)
     PO.accumulate(want, (0, 0, 112, 112), PO.one_hot(PO.nearest_resize(big[0].cpu().numpy().astype(np.int64), 112), 4))
     assert np.array_equal(c2.cpu().numpy(), want)
+    # non-dyadic ratios: OpenCV's resizeNN index rule in DOUBLE (floor(dst * (1 / (dsize / ssize)))); a float32
+    # evaluation differs on 7 rows / columns each for 448 -> 384 / 640 / 768
+    for cs in (384, 640, 100):
+        cN = torch.zeros(cs, cs, 4, dtype=torch.uint8, device=DEV)
+        ops.vote_paste(cN, big, torch.tensor([[0, 0, cs, cs]], dtype=torch.int32, device=DEV), cs)
+        wantN = np.zeros((cs, cs, 4), np.uint8)
+        PO.accumulate(wantN, (0, 0, cs, cs), PO.one_hot(PO.nearest_resize(big[0].cpu().numpy().astype(np.int64), cs), 4))
+        assert np.array_equal(cN.cpu().numpy(), wantN), cs
     # uint8 wrap at 256 votes
     c3 = torch.full((16, 16, 4), 255, dtype=torch.uint8, device=DEV)
     ops.vote_paste(c3, preds[:1], torch.tensor([[0, 0, 16, 16]], dtype=torch.int32, device=DEV), 16)

@@ -1,7 +1,15 @@
 """Summarise rocprofv3 --pmc CSVs (run on the GPU box): per kernel family the per-launch HBM bytes
 (FETCH_SIZE x2 on gfx950 for wide coalesced reads, WRITE_SIZE), MFMA / LDS busy fractions and effective clock.
 usage: python tools/pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <dir_grbm> <out.json>"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, hashlib, json, pathlib, re, sys
+
+
+def csrc_sha():  # same hash as bench.py: ties this summary to the kernel sources it was measured on
+    h = hashlib.sha256()
+    for f in sorted((pathlib.Path(__file__).resolve().parents[1] / "beach_seg_amd" / "csrc").glob("*")):
+        if f.suffix in (".hpp", ".hip"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def load(d):
@@ -35,5 +43,6 @@ for k in sd:
     }
     o = out[k]
     o["hbm_GBps"] = (o["hbm_fetch_MB_per_launch"] + o["hbm_write_MB_per_launch"]) * 1e6 / (o["avg_us"] * 1e3) if o["avg_us"] else 0
+out["_meta"] = {"csrc_sha": csrc_sha(), "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE x1; one rocprofv3 --pmc pass per counter group"}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print("wrote", sys.argv[5], len(out), "kernels")
