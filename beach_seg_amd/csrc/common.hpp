@@ -63,6 +63,13 @@ template <> DEVI bf16x4 pack4<bf16_t>(float a, float b, float c, float d) {
   return bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
 
+// two floats -> one 32-bit word of two 16-bit values (16-bit dtypes only)
+template <typename T> DEVI unsigned pack2(float a, float b);
+template <> DEVI unsigned pack2<bf16_t>(float a, float b) {
+  const bf16x2 v = bf16x2{(bf16_t)a, (bf16_t)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
 // chunk from 8 (bf16) or 4 (f32) floats held in two f32x4 (second ignored for f32)
 DEVI void chunk_from_f32(bf16x8& c, const float* v) {
 #pragma unroll
@@ -76,6 +83,23 @@ DEVI void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ---- LDS reads the compiler does not count (software-pipelined fragment reads at one wave per SIMD: hipcc's own
+//      waits collapse to lgkmcnt(0) right behind the prefetch).  The caller owns the wait: `lds_wait<N>()` leaves the N
+//      youngest LDS operations in flight (LDS reads return in order) and fences the scheduler so that no consumer moves
+//      above it (guide section 5.7 item 1, form iii).
+DEVI unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)p;
+}
+DEVI f32x4 lds_read16_nowait(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int N> DEVI void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 // ---- wave-level reductions (64 lanes)
 DEVI float wave_sum(float v) {

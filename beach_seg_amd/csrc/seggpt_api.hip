@@ -180,6 +180,39 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   launch_gemm<T, AM, EPI>(g, st);
 }
 
+// 3x3 conv launch: 16-bit dtypes take the persistent ring kernel (decoder.hpp), f32 the halo-tile kernel.
+static int conv_row_split(int base_items, int steps_total) {
+  int best = 1;
+  double best_t = 1e30;
+  for (int n = 1; n <= 16 && n <= steps_total; ++n) {
+    const long items = (long)base_items * n, rounds = (items + 255) / 256;
+    const double t = rounds * ((double)steps_total / n + 1.2);  // + pipeline fill of an item (10 rows before the first MFMA)
+    if (t < best_t - 1e-9) { best_t = t; best = n; }
+  }
+  return best;
+}
+template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int B, int ty0, hipStream_t st) {
+  static const bool ring_env = !getenv("BSG_CONV_NO_RING");
+  if constexpr (sizeof(T) == 2) {
+    if (ring_env) {
+      static bool once = (allow_lds(conv3x3_ring_kernel<T, MODE>, CR_LDS), true);
+      (void)once;
+      ConvRingArgs r{};
+      r.c = a; r.y_begin = ty0 * CONV_TR; r.batch = B;
+      const int strips = a.W / 32, steps_total = (a.H - r.y_begin) / CR_ROWS;
+      r.nsplit = conv_row_split(B * strips, steps_total);
+      const int items = B * strips * r.nsplit;
+      hipLaunchKernelGGL((conv3x3_ring_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(256), CR_LDS, st, r);
+      return;
+    }
+  }
+  static bool once2 = (allow_lds(conv3x3_kernel<T, MODE>, CONV_HALO * 64 * sizeof(T)), true);
+  (void)once2;
+  ConvArgs b = a;
+  b.ty0 = ty0;
+  hipLaunchKernelGGL((conv3x3_kernel<T, MODE>), dim3(a.W / 32, a.H / CONV_TR - ty0, B), dim3(256), CONV_HALO * 64 * sizeof(T), st, b);
+}
+
 template <typename T> struct Ctx {
   const bsg_model* m;
   hipStream_t st;
@@ -342,11 +375,8 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     a.in = feat; a.w = m->gw(9); a.bias = (const float*)m->gw(11); a.out = train ? c.template at<T>("conv_out") : nullptr;
     a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
     a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
-    const int lds = CONV_HALO * 64 * sizeof(T);
-    static bool once = (allow_lds(conv3x3_kernel<T, CONV_FWD_FUSED>, CONV_HALO * 64 * sizeof(T)), true);
-    (void)once;
     ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * 64 * 64);
-    hipLaunchKernelGGL((conv3x3_kernel<T, CONV_FWD_FUSED>), dim3(a.W / 32, a.H / CONV_TR, B), dim3(256), lds, st, a);
+    launch_conv<T, CONV_FWD_FUSED>(a, B, 0, st);
     CHECK_LAUNCH();
   }
   return 0;
@@ -388,13 +418,10 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
                        (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0);
     CHECK_LAUNCH();
     ConvArgs a{};
-    a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps; a.ty0 = ty0;
-    const int lds = CONV_HALO * 64 * sizeof(T);
-    static bool once = (allow_lds(conv3x3_kernel<T, CONV_PLAIN>, CONV_HALO * 64 * sizeof(T)), true);
-    (void)once;
+    a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
     {
       ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * CONV_TR) * W * 9 * 64 * 64);
-      hipLaunchKernelGGL((conv3x3_kernel<T, CONV_PLAIN>), dim3(W / 32, H / CONV_TR - ty0, B), dim3(256), lds, st, a);
+      launch_conv<T, CONV_PLAIN>(a, B, ty0, st);
     }
     CHECK_LAUNCH();
     if (ph0 > 0) {  // token rows < ph0 receive exactly zero

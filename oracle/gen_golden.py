@@ -33,6 +33,7 @@ from beach_seg_amd.weights import SegGptGeometry, counter_noise, synth_state_dic
 from oracle.gen_inputs import synth_inputs  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
+PEAK_GAIN = 8.0  # q / k / rel-pos gain of the peaked-attention fixture (oracle/gen_inputs.peaked_state_dict)
 
 
 def import_reference():
@@ -86,8 +87,37 @@ def hf_model(g: SegGptGeometry, sd: dict):
 
 
 
-def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int, tag: str, full: bool):
-    sd = synth_state_dict(g, seed=wseed)
+def attention_peak_stats(m, g, pix, prm, prompt_masks) -> dict:
+    """Row-max logit and row-max probability of every attention block of the HF module (hooks on the softmax inputs are
+    not exposed, so the logits are re-formed from each block's own qkv output the way HF:313-331 does)."""
+    stats = {"max_logit": [], "mean_rowmax_prob": []}
+    hooks = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        B_, H_, W_, _ = x.shape
+        qkv = mod.qkv(x).reshape(B_, H_ * W_, 3, mod.num_attention_heads, -1).permute(2, 0, 3, 1, 4)
+        q, k, _ = qkv.reshape(3, B_ * mod.num_attention_heads, H_ * W_, -1).unbind(0)
+        attn = (q * mod.scale) @ k.transpose(-2, -1)
+        attn = mod.add_decomposed_rel_pos(attn, q, mod.rel_pos_h, mod.rel_pos_w, (H_, W_), (H_, W_))
+        stats["max_logit"].append(float((attn.max(-1).values - attn.mean(-1)).max()))
+        stats["mean_rowmax_prob"].append(float(torch.softmax(attn.float(), -1).max(-1).values.mean()))
+
+    for layer in m.model.encoder.layers:
+        hooks.append(layer.attention.register_forward_hook(hook))
+    with torch.no_grad():
+        m(pixel_values=pix, prompt_pixel_values=prm, prompt_masks=prompt_masks, embedding_type="instance")
+    for h in hooks:
+        h.remove()
+    return stats
+
+
+def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int, tag: str, full: bool, peaked: float = 0.0):
+    if peaked:
+        from oracle.gen_inputs import peaked_state_dict
+        sd = peaked_state_dict(g, wseed, peaked)
+    else:
+        sd = synth_state_dict(g, seed=wseed)
     m = hf_model(g, sd)
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, iseed)
     bare = ref_model.PromptModel.__new__(ref_model.PromptModel)  # no __init__: needs hub weights
@@ -128,6 +158,13 @@ def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int
                    masks_slice=masks.to(torch.uint8).numpy()[:, ::st, ::st], stride=st,
                    pred_l2=float(np.sqrt((pred_np.astype(np.float64) ** 2).sum())),
                    grad_l2=float(np.sqrt((grad_np.astype(np.float64) ** 2).sum())))
+    if peaked:
+        st_ = attention_peak_stats(m, g, pix, prm.detach(), prompt_masks)
+        rec.update(peak_gain=peaked, max_logit_above_row_mean=np.array(st_["max_logit"]),
+                   mean_rowmax_prob=np.array(st_["mean_rowmax_prob"]))
+        print(tag, "max logit above row mean per layer", [round(v, 1) for v in st_["max_logit"]],
+              "mean row-max prob", [round(v, 3) for v in st_["mean_rowmax_prob"]])
+        assert max(st_["max_logit"]) > 20.0, "the peaked fixture must drive logits past 20"
     np.savez_compressed(GOLD / f"{tag}.npz", **rec)
     print(tag, "loss", float(loss), "pred_l2", float(pred.norm()), "grad_l2", float(grad.norm()))
     return m, sd
@@ -221,15 +258,20 @@ def run_predict_glue(ref_predict):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-vitl", action="store_true")
+    ap.add_argument("--only", default="", help="generate one case only: small_peaked")
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
     ref_model, ref_ml, ref_predict = import_reference()
+    if args.only == "small_peaked":
+        run_e2e(ref_model, ref_ml, SegGptGeometry.small(), B=2, wseed=2, iseed=6, tag="small_peaked_e2e", full=False, peaked=PEAK_GAIN)
+        return
     run_wrapper(ref_model, ref_ml)
     run_predict_glue(ref_predict)
     run_e2e(ref_model, ref_ml, SegGptGeometry.tiny(), B=2, wseed=1, iseed=3, tag="tiny_e2e", full=True)
     run_feature_ensemble(SegGptGeometry.tiny(), wseed=1, iseed=4)
     run_e2e(ref_model, ref_ml, SegGptGeometry.small(), B=2, wseed=2, iseed=5, tag="small_e2e", full=False)
+    run_e2e(ref_model, ref_ml, SegGptGeometry.small(), B=2, wseed=2, iseed=6, tag="small_peaked_e2e", full=False, peaked=PEAK_GAIN)
     if not args.skip_vitl:
         run_e2e(ref_model, ref_ml, SegGptGeometry.vit_large(), B=1, wseed=0, iseed=7, tag="vitl_e2e", full=False)
 

@@ -4,10 +4,15 @@ seeded inputs.
 
 Tolerances.  north_star: "within 1e-3 rel fp32 (argmax masks bit-exact)".
   * dtype float32 (parity mode, exact-f32 MFMA): max-abs error <= 1e-4 of the tensor's max-abs (measured ~1e-6),
-    loss to 1e-5 rel, decoded masks BIT-EXACT.
-  * dtype bfloat16 (throughput mode; bf16 operands cannot reach 1e-3 through 24 layers): max-abs error <= 3e-2
-    of max-abs (measured ~5e-3), loss to 1e-3 rel, masks: >= 99.5 % of pixels equal and bit-exact on every pixel
-    whose best/second-best palette distance gap exceeds the error bound.
+    loss to 1e-5 rel, decoded masks BIT-EXACT.  This is the mode that meets north_star's bar.
+  * dtype bfloat16 (throughput mode).  bf16 operands (8 significant bits, unit round-off 2^-9 per MFMA operand)
+    cannot reach 1e-3 through 24 layers: the per-stage budget (`tools/error_budget.py`,
+    `profiles/r2_error_budget.json`) shows the rms-relative error of the residual stream growing 2.5e-3 (after ONE
+    layer) -> 6.2e-3 (after 24), with the patch embedding itself exact (7e-6) since it runs at split precision.
+    The bars below are ~1.5x what each geometry measures (printed by the tests as `[measured]`).  Masks: every pixel
+    whose two nearest palette colours are further apart than the proven bound 2 * delta * ||p_j - p_k||_1
+    (delta = the max-abs error the test has just asserted; the e^2 terms of the two squared distances cancel) must
+    decode identically, and the number of differing pixels is asserted as a COUNT.
 """
 import zlib
 
@@ -19,7 +24,7 @@ from beach_seg_amd import ops
 from beach_seg_amd.weights import SegGptGeometry, synth_state_dict
 from oracle import predict_oracle as PO
 from oracle import seggpt_oracle as O
-from oracle.gen_inputs import synth_inputs
+from oracle.gen_inputs import peaked_state_dict, synth_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -34,21 +39,24 @@ def relmax(a, b):
 _models = {}
 
 
-def model_for(gname, wseed, dtype):
+def model_for(gname, wseed, dtype, peak_gain=0.0):
     from beach_seg_amd.seggpt import SegGptNative
 
-    key = (gname, wseed, dtype)
+    key = (gname, wseed, dtype, peak_gain)
     if key not in _models:
         _models.clear()  # one resident model at a time
         g = getattr(SegGptGeometry, gname)()
-        dev_sd = synth_state_dict(g, seed=wseed, device=DEV if gname == "vit_large" else "cpu")
+        if peak_gain:
+            dev_sd = peaked_state_dict(g, wseed, peak_gain)
+        else:
+            dev_sd = synth_state_dict(g, seed=wseed, device=DEV if gname == "vit_large" else "cpu")
         _models[key] = SegGptNative(dev_sd, g, device=DEV, dtype=dtype)
     return _models[key]
 
 
 def run_case(gname, rec, B, dtype):
     g = getattr(SegGptGeometry, gname)()
-    model = model_for(gname, int(rec["wseed"]), dtype)
+    model = model_for(gname, int(rec["wseed"]), dtype, float(rec["peak_gain"]) if "peak_gain" in rec.files else 0.0)
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, int(rec["iseed"]))
     pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
     lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
@@ -64,70 +72,97 @@ def run_case(gname, rec, B, dtype):
     return out.pred_masks.detach().cpu(), loss.item(), p.grad.cpu(), masks.cpu(), pn
 
 
-def margin_ok(pred, pn, masks, ref_masks, tol):
-    """Pixels whose two smallest palette distances differ by more than `tol` must decode identically."""
-    H = pred.shape[2] // 2
-    x = pred[:, :, H:, :].permute(0, 2, 3, 1)
+def check_masks_by_margin(pred_ref_bottom, pn, masks, ref_masks, delta, max_mismatch, tag):
+    """pred_ref_bottom (B,3,h,w): the reference prediction on the query half (or a strided slice of it); masks /
+    ref_masks (B,h,w).  With |pred - pred_ref| <= delta everywhere, the gap between the squared distances to two palette
+    colours moves by at most 2 * delta * ||p_j - p_k||_1, so pixels with a larger gap MUST decode identically."""
+    x = torch.as_tensor(pred_ref_bottom).permute(0, 2, 3, 1)
     d = ((x[:, :, :, None, :] - pn[:, None, None, :, :]) ** 2).sum(-1)
     top2 = d.topk(2, dim=-1, largest=False).values
-    safe = (top2[..., 1] - top2[..., 0]) > tol
-    return bool((masks[safe] == ref_masks[safe]).all())
+    l1 = (pn[:, :, None, :] - pn[:, None, :, :]).abs().sum(-1).amax(dim=(1, 2))  # (B,) worst palette pair
+    bound = (2.0 * delta * l1)[:, None, None]
+    safe = (top2[..., 1] - top2[..., 0]) > bound
+    masks, ref_masks = torch.as_tensor(masks).long(), torch.as_tensor(ref_masks).long()
+    bad = masks != ref_masks
+    print(f"[measured] {tag}: {int(bad.sum())} of {bad.numel()} mask pixels differ; {float(safe.float().mean()) * 100:.2f} % of the "
+          f"pixels are outside the margin bound {float(bound.max()):.3f}")
+    assert not bool((bad & safe).any()), "a pixel outside the proven margin decoded differently"
+    assert int(bad.sum()) <= max_mismatch, f"{int(bad.sum())} mask pixels differ (allowed {max_mismatch})"
 
 
-TOL = {torch.float32: dict(t=1e-4, loss=1e-5), torch.bfloat16: dict(t=3e-2, loss=1e-3)}
+# f32: the north_star bar.  bf16: ~1.5 x the measured error of each geometry (see the module docstring), `mm` = allowed
+# number of differing mask pixels (of the pixels the fixture holds: all for tiny, every 8th row / column otherwise).
+TOL = {
+    torch.float32: {k: dict(t=1e-4, loss=1e-5, mm=0) for k in ("tiny", "small", "small_peaked", "vit_large")},
+    torch.bfloat16: {
+        "tiny": dict(t=8e-3, loss=1e-3, mm=24),          # measured pred 4.1e-3 / grad 5.0e-3, 9 of 8192 mask pixels
+        "small": dict(t=1e-2, loss=1e-3, mm=8),          # 5.0e-3 / 6.4e-3, 1 of 6272
+        "small_peaked": dict(t=1.7e-2, loss=1e-3, mm=8),  # 5.4e-3 / 1.13e-2, 0 of 6272
+        "vit_large": dict(t=1.6e-2, loss=1e-3, mm=8),    # 7.8e-3 / 1.03e-2, 0 of 3136
+    },
+}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tiny_end_to_end_vs_reference_vectors(golden_dir, dtype):
     rec = np.load(golden_dir / "tiny_e2e.npz")
     pred, loss, grad, masks, pn = run_case("tiny", rec, 2, dtype)
-    tol = TOL[dtype]
-    assert relmax(pred, rec["pred"]) < tol["t"]
+    tol = TOL[dtype]["tiny"]
+    e_pred, e_grad = relmax(pred, rec["pred"]), relmax(grad, rec["grad"])
+    print(f"[measured] tiny {dtype}: pred {e_pred:.2e} grad {e_grad:.2e} loss {abs(loss - float(rec['loss'])) / abs(float(rec['loss'])):.1e}")
+    assert e_pred < tol["t"] and e_grad < tol["t"]
     assert abs(loss - float(rec["loss"])) < tol["loss"] * abs(float(rec["loss"]))
-    assert relmax(grad, rec["grad"]) < tol["t"]
     ref_masks = torch.from_numpy(rec["masks"]).long()
     if dtype == torch.float32:
         assert torch.equal(masks, ref_masks)  # bit-exact
     else:
-        assert (masks == ref_masks).float().mean().item() > 0.995
-        assert margin_ok(torch.from_numpy(rec["pred"]), pn, masks, ref_masks, 0.2)
+        H = pred.shape[2] // 2
+        delta = tol["t"] * float(np.abs(rec["pred"]).max())
+        check_masks_by_margin(rec["pred"][:, :, H:, :], pn, masks, ref_masks, delta, tol["mm"], "tiny bf16")
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_small_end_to_end_real_token_grid(golden_dir, dtype):
-    """56 x 28 token grid (1568 tokens, the reference geometry: padded key slots, 13 query blocks, 28 key tiles)."""
-    rec = np.load(golden_dir / "small_e2e.npz")
-    pred, loss, grad, masks, pn = run_case("small", rec, 2, dtype)
-    tol, st = TOL[dtype], int(rec["stride"])
-    assert relmax(pred[:, :, ::st, ::st], rec["pred_slice"]) < tol["t"]
+def _sliced_case(golden_dir, fixture, gname, B, dtype):
+    rec = np.load(golden_dir / fixture)
+    key = "small_peaked" if "peaked" in fixture else gname
+    pred, loss, grad, masks, pn = run_case(gname, rec, B, dtype)
+    tol, st = TOL[dtype][key], int(rec["stride"])
+    e_pred, e_grad = relmax(pred[:, :, ::st, ::st], rec["pred_slice"]), relmax(grad[:, :, ::st, ::st], rec["grad_slice"])
+    e_pl2 = abs(float(pred.double().norm()) - float(rec["pred_l2"])) / float(rec["pred_l2"])
+    e_gl2 = abs(float(grad.double().norm()) - float(rec["grad_l2"])) / float(rec["grad_l2"])
+    print(f"[measured] {key} {dtype}: pred {e_pred:.2e} grad {e_grad:.2e} |pred|2 {e_pl2:.1e} |grad|2 {e_gl2:.1e} "
+          f"loss {abs(loss - float(rec['loss'])) / abs(float(rec['loss'])):.1e}")
+    assert e_pred < tol["t"] and e_grad < tol["t"]
     assert abs(loss - float(rec["loss"])) < tol["loss"] * abs(float(rec["loss"]))
-    assert relmax(grad[:, :, ::st, ::st], rec["grad_slice"]) < tol["t"]
-    assert abs(float(pred.double().norm()) - float(rec["pred_l2"])) < tol["t"] * float(rec["pred_l2"])
-    assert abs(float(grad.double().norm()) - float(rec["grad_l2"])) < 2 * tol["t"] * float(rec["grad_l2"])
+    assert e_pl2 < tol["t"] and e_gl2 < 2 * tol["t"]
     m8 = masks.numpy().astype(np.uint8)
     if dtype == torch.float32:
         assert np.array_equal(m8[:, ::st, ::st], rec["masks_slice"])
         assert zlib.crc32(m8.tobytes()) == int(rec["masks_crc"])  # every pixel bit-exact
     else:
-        assert (m8[:, ::st, ::st] == rec["masks_slice"]).mean() > 0.995
+        H = pred.shape[2] // 2
+        delta = tol["t"] * float(np.abs(rec["pred_slice"]).max())
+        check_masks_by_margin(rec["pred_slice"][:, :, H // st:, :], pn, m8[:, ::st, ::st], rec["masks_slice"], delta, tol["mm"],
+                              f"{key} bf16")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_end_to_end_real_token_grid(golden_dir, dtype):
+    """56 x 28 token grid (1568 tokens, the reference geometry: padded key slots, 13 query blocks, 28 key tiles)."""
+    _sliced_case(golden_dir, "small_e2e.npz", "small", 2, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_small_peaked_attention_vs_reference_vectors(golden_dir, dtype):
+    """The same grid with PEAKED attention (q / k / rel-pos x 8: logits 24-28 above the row mean, mean row-max
+    probability ~0.4, as a trained checkpoint produces): drives the online-softmax rescale path and the exp2 range that
+    the sigma = 0.02 fixtures (near-uniform rows) never reach.  Vector generated by the HF module itself."""
+    _sliced_case(golden_dir, "small_peaked_e2e.npz", "small", 2, dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_vit_large_vs_reference_vectors(golden_dir, dtype):
     """Full reference geometry (ViT-L, 24 layers, 370.7 M parameters), B=1."""
-    rec = np.load(golden_dir / "vitl_e2e.npz")
-    pred, loss, grad, masks, pn = run_case("vit_large", rec, 1, dtype)
-    tol, st = TOL[dtype], int(rec["stride"])
-    assert relmax(pred[:, :, ::st, ::st], rec["pred_slice"]) < tol["t"]
-    assert abs(loss - float(rec["loss"])) < tol["loss"] * abs(float(rec["loss"]))
-    assert relmax(grad[:, :, ::st, ::st], rec["grad_slice"]) < tol["t"]
-    assert abs(float(pred.double().norm()) - float(rec["pred_l2"])) < tol["t"] * float(rec["pred_l2"])
-    assert abs(float(grad.double().norm()) - float(rec["grad_l2"])) < 2 * tol["t"] * float(rec["grad_l2"])
-    m8 = masks.numpy().astype(np.uint8)
-    if dtype == torch.float32:
-        assert zlib.crc32(m8.tobytes()) == int(rec["masks_crc"])
-    else:
-        assert (m8[:, ::st, ::st] == rec["masks_slice"]).mean() > 0.99
+    _sliced_case(golden_dir, "vitl_e2e.npz", "vit_large", 1, dtype)
 
 
 def test_against_oracle_semantic_embedding_and_no_labels():
@@ -386,7 +421,7 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
         out = model(pixel_values=torch.from_numpy(rec["pixel_values"]).to(DEV),
                     prompt_pixel_values=torch.from_numpy(rec["prompt_pixel_values"]).to(DEV),
                     prompt_masks=torch.from_numpy(rec["prompt_masks"]).to(DEV), feature_ensemble=True)
-    assert relmax(out.pred_masks, rec["pred"]) < TOL[dtype]["t"]
+    assert relmax(out.pred_masks, rec["pred"]) < TOL[dtype]["tiny"]["t"]
     if dtype == torch.float32:  # the whole few-shot crop step of src/predict_no_prompt.py:283-301 against the oracle's decode
         from beach_seg_amd.predict import ensemble_predict
         from oracle import predict_oracle as PO
@@ -398,10 +433,12 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
         assert (got.cpu() == want).float().mean().item() > 0.99  # pred differs from HF's by ~1e-6: near-ties may flip
 
 
-def test_wide_grid_and_wide_encoder_vs_oracle():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
     """BASELINE config 5 geometry class: 64 x 32 token grid (1024 x 512 canvas: no padded key slots, Hp = 64) and a
     2048-wide encoder with 32 heads; 2 layers so the CPU oracle finishes in seconds.  No reference checkpoint of this
-    shape exists, so parity is against the oracle (itself pinned on the reference geometry)."""
+    shape exists, so parity is against the oracle (itself pinned on the reference geometry).  bf16 is the dtype
+    config 5 names (Hp = 64 with no padded key slots in the transposing-read attention path)."""
     import dataclasses
 
     from beach_seg_amd.seggpt import SegGptNative
@@ -411,7 +448,7 @@ def test_wide_grid_and_wide_encoder_vs_oracle():
                             intermediate_hidden_state_indices=(0, 1))
     _models.clear()
     sd = synth_state_dict(g, seed=5)
-    model = SegGptNative(sd, g, device=DEV, dtype=torch.float32)
+    model = SegGptNative(sd, g, device=DEV, dtype=dtype)
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, 1, 9)
     pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
     lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
@@ -424,7 +461,9 @@ def test_wide_grid_and_wide_encoder_vs_oracle():
     out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
     loss = ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference")
     loss.backward()
-    assert relmax(out.pred_masks, pred_ref) < 1e-4
-    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
-    assert relmax(p.grad, grad_ref) < 1e-4
+    t, tl = (1e-4, 1e-5) if dtype == torch.float32 else (1.2e-2, 1e-3)  # bf16, 2 wide layers: measured 7.3e-3 / 7.3e-3
+    print(f"[measured] config-5 class {dtype}: pred {relmax(out.pred_masks, pred_ref):.2e} grad {relmax(p.grad, grad_ref):.2e}")
+    assert relmax(out.pred_masks, pred_ref) < t
+    assert abs(loss.item() - loss_ref.item()) < tl * abs(loss_ref.item())
+    assert relmax(p.grad, grad_ref) < t
     del model

@@ -14,7 +14,11 @@ from oracle.gen_inputs import synth_inputs
 
 
 def _e2e(g, rec, B):
-    w = synth_state_dict(g, seed=int(rec["wseed"]))
+    if "peak_gain" in rec.files:
+        from oracle.gen_inputs import peaked_state_dict
+        w = peaked_state_dict(g, int(rec["wseed"]), float(rec["peak_gain"]))
+    else:
+        w = synth_state_dict(g, seed=int(rec["wseed"]))
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, int(rec["iseed"]))
     assert np.array_equal(pal.numpy(), rec["palette"])
     pn = O.palette_norm(pal)
@@ -56,6 +60,23 @@ def test_small_end_to_end(golden_dir):
     assert abs(float(grad.double().norm()) - float(rec["grad_l2"])) < 1e-3 * float(rec["grad_l2"])
     m8 = masks.numpy().astype(np.uint8)
     assert np.array_equal(m8[:, ::st, ::st], rec["masks_slice"])
+    assert zlib.crc32(m8.tobytes()) == int(rec["masks_crc"])
+
+
+def test_small_peaked_attention_end_to_end(golden_dir):
+    """q / k / rel-pos scaled x8: logits reach 24-28 above the row mean and the mean row-max probability is ~0.4, so
+    the softmax is peaked the way a trained checkpoint's is (HF-generated vector, `oracle/gen_golden.py`)."""
+    rec = np.load(golden_dir / "small_peaked_e2e.npz")
+    assert rec["max_logit_above_row_mean"].min() > 20
+    g = SegGptGeometry.small()
+    pred, loss, grad, masks, _, _ = _e2e(g, rec, 2)
+    st = int(rec["stride"])
+    np.testing.assert_allclose(pred.numpy()[:, :, ::st, ::st], rec["pred_slice"], rtol=1e-4, atol=5e-5)
+    assert abs(loss - float(rec["loss"])) < 1e-5 * abs(float(rec["loss"]))
+    gs = rec["grad_slice"]
+    assert np.abs(grad.numpy()[:, :, ::st, ::st] - gs).max() < 1e-3 * np.abs(gs).max()
+    assert abs(float(grad.double().norm()) - float(rec["grad_l2"])) < 1e-3 * float(rec["grad_l2"])
+    m8 = masks.numpy().astype(np.uint8)
     assert zlib.crc32(m8.tobytes()) == int(rec["masks_crc"])
 
 
