@@ -439,8 +439,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // P^T = exp2(S^T c2 - lse2) -> dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.
 // The rel-pos gradients fall out of the layout: d relw[q][kw] accumulates per accumulator REGISTER over the
 // whole key loop (register <-> kw), d relh[q][2t+b] is the per-block sum.
+#ifdef BSG_DIAG_STAMPS_ATTN
+__device__ unsigned long long bsg_attn_stamps[8];
+#define ATTN_STAMP(i) do { if (threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&bsg_attn_stamps[i], (unsigned long long)(t_ - st_prev)); st_prev = t_; } } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
 template <typename T, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+#ifdef BSG_DIAG_STAMPS_ATTN
+  long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
@@ -479,6 +488,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   if (active)
     relpos_wave_tables<T>(qf, a.rel_cat, a.hp, a.wp, qh, qw, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp, 1.0f / a.scale,
                           (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
+  ATTN_STAMP(0);  // loads of q / dO + rel-pos tables
   // publish the key-major copies the dK/dV kernel streams (lane = key there): 128-byte row segments per half-wave
   if (q0 + col < ((a.N + 63) & ~63)) {
     const bool real = q0 + col < a.N;  // tail columns up to the dK/dV tile boundary: -inf bias, i.e. P = 0
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
       a.delta[sh * npad + q0 + col] = 0.f;
     }
   }
+  ATTN_STAMP(1);  // publish relwT / relhT
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   const float c2 = a.scale * 1.44269504088896340736f;
   const float lse = a.lse2[sh * npad + q];
@@ -527,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     if constexpr (!TR) dma_tile_issue<T>(k_l + 2 * C::TILE, wave, ktbase + t * 64 * es, ktoff);
   };
 
+  ATTN_STAMP(2);  // delta, DMA offsets
   f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
@@ -599,6 +611,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     if (h == 0) { relh_q[2 * t] = drh[0]; relh_q[2 * t + 1] = drh[1]; }  // both were read a tile ago
   }
+  ATTN_STAMP(3);  // key loop
   // rel-pos gradient straight into dq: d relw goes to a [32][33] image in this wave's slice of the (now idle) tile area
   __syncthreads();
   if (!active) return;
@@ -610,6 +623,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   f32x16 racc[2];
   relpos_wave_bwd<T>(racc, a.rel_catT, a.hp, a.wp, qh, qw, q0 / a.wp, min(q0 + 31, a.N - 1) / a.wp,
                      relh_q - col * relh_stride(a.hp), image_w, lane);
+  ATTN_STAMP(4);  // rel-pos gradient
   if (q0 + col < a.N) {
     T* orow = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
 #pragma unroll
@@ -620,6 +634,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             pack4<T>(fmaf(dqt[d][4 * i], a.scale, racc[d][4 * i]), fmaf(dqt[d][4 * i + 1], a.scale, racc[d][4 * i + 1]),
                      fmaf(dqt[d][4 * i + 2], a.scale, racc[d][4 * i + 2]), fmaf(dqt[d][4 * i + 3], a.scale, racc[d][4 * i + 3]));
   }
+#ifdef BSG_DIAG_STAMPS_ATTN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ATTN_STAMP(5);  // dq store
+  if (threadIdx.x == 0) atomicAdd(&bsg_attn_stamps[7], 1ull);
+#endif
 }
 
 // ------------------------------------------------------------------------------------- backward: dK, dV

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -95,6 +96,23 @@ DEVI f32x4 lds_read16_nowait(unsigned addr) {
   f32x4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
+}
+template <int OFF> DEVI f32x4 lds_read16_nw(unsigned addr) {  // ds_read_b128 with an immediate byte offset
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+template <int OFF> DEVI f32x2 lds_read8tr_nw(unsigned addr) {  // transposing 4 x 16-bit read (see attention.hpp lds_tr_chunk)
+  f32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- loop indices usable as asm immediates
+template <int I, int N, typename F> DEVI void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 template <int N> DEVI void lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N) : "memory");

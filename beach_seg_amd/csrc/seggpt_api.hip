@@ -776,6 +776,73 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
   return 0;
 }
 
+
+size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp) {
+  const size_t npad = (size_t)hp * 32;
+  // fwd key-major relh | relhT | relwT | delta
+  return (size_t)S * nh * npad * 4 * ((size_t)hp + hp + 32 + 1) + 1024;
+}
+
+int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
+                     const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
+                     size_t scratch_bytes) {
+  typedef bf16_t T;
+  if (!qkv || !rel_cat || !out || !lse2 || !scratch) return fail("bsg_op_attention: null argument");
+  if ((which & 6) && (!rel_catT || !dout || !dqkv)) return fail("bsg_op_attention: backward needs rel_catT, dout, dqkv");
+  if (hp % 2 || hp > 64 || wp > 32 || wp % 4) return fail("bsg_op_attention: bad token grid %d x %d", hp, wp);
+  if (scratch_bytes < bsg_op_attention_scratch_bytes(S, nh, hp)) return fail("bsg_op_attention: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = hp * wp, D = nh * 64;
+  const size_t npad = (size_t)hp * 32, per = (size_t)S * nh * npad;
+  float* relh_s = (float*)scratch;
+  float* relhT = relh_s + per * hp;
+  float* relwT = relhT + per * hp;
+  float* delta = relwT + per * 32;
+  const T* q = (const T*)qkv;
+  static bool once = (allow_lds(attn_fwd_kernel<T, true>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, true>, 160 * 1024),
+                      allow_lds(attn_bwd_dkv_kernel<T, true>, 2 * DkvK<T, true>::STAGE), true);
+  (void)once;
+  const int relh_lds = 4 * 32 * (hp | 1) * 4;
+  if (which & 1) {
+    AttnArgs a{};
+    a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld = 3 * D; a.rel_cat = rel_cat; a.relhT = relh_s; a.out = out; a.ldo = D;
+    a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = 0.125f;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, true>), dim3(((N + 127) / 128) * nh * S), dim3(256),
+                       std::max(4 * AttnK<T>::TILE, relh_lds), st, a);
+    CHECK_LAUNCH();
+  }
+  if (which & 2) {
+    AttnArgs a{};
+    a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld = 3 * D; a.dout = dout; a.ldo = D; a.rel_cat = rel_cat; a.rel_catT = rel_catT;
+    a.relhT = relhT; a.relwT = relwT; a.lse2 = lse2; a.delta = delta; a.out = out; a.dq = dqkv;
+    a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = 0.125f;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), dim3(((N + 127) / 128) * nh * S), dim3(256),
+                       4 * AttnK<T>::TILE + relh_lds, st, a);
+    CHECK_LAUNCH();
+#ifdef BSG_DIAG_STAMPS_ATTN
+    {
+      (void)hipStreamSynchronize(st);
+      unsigned long long hbuf[8], z[8] = {0};
+      (void)hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(bsg_attn_stamps), sizeof(hbuf));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(bsg_attn_stamps), z, sizeof(z));
+      const double n = (double)std::max<unsigned long long>(hbuf[7], 1);
+      fprintf(stderr, "[dq stamps] per workgroup (wave 0, shader cycles): load+tables %.0f, publish %.0f, delta %.0f, key loop %.0f, rel-pos grad %.0f, store %.0f\n",
+              hbuf[0] / n, hbuf[1] / n, hbuf[2] / n, hbuf[3] / n, hbuf[4] / n, hbuf[5] / n);
+    }
+#endif
+  }
+  if (which & 4) {
+    AttnBwdKvArgs k{};
+    k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
+    k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
+    k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    constexpr int lds_kv = 2 * DkvK<T, true>::STAGE;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true>), dim3(((hp + 7) / 8) * nh * S), dim3(512), lds_kv, st, k);
+    CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 int bsg_vote_paste(void* stream, int n_crops, const uint8_t* masks, int hin, int win, int crop, const int32_t* crops,
                    uint8_t* counter, int mh, int mw, int K) {
   if (!masks || !crops || !counter) return fail("bsg_vote_paste: null argument");

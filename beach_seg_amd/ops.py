@@ -236,3 +236,19 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) 
         N.check(lib.bsg_op_gemm(_stream(), 0 if a.dtype == torch.float32 else 1, M, w.shape[0], K, _ptr(a.contiguous()),
                                 _ptr(w.contiguous()), _ptr(bias), _ptr(out)))
     return out
+
+
+def attention_scratch(S: int, nh: int, hp: int, device) -> torch.Tensor:
+    return torch.zeros(N.load().bsg_op_attention_scratch_bytes(S, nh, hp), dtype=torch.uint8, device=device)
+
+
+def attention(which: int, qkv: torch.Tensor, rel_cat: torch.Tensor, S: int, nh: int, hp: int, wp: int, out: torch.Tensor,
+              lse2: torch.Tensor, scratch: torch.Tensor, rel_catT: torch.Tensor | None = None,
+              dout: torch.Tensor | None = None, dqkv: torch.Tensor | None = None) -> None:
+    """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV.  bf16 tensors:
+    qkv (S*N, 3*nh*64), rel_cat ([LH+LW], 64) / rel_catT, dout / out (S*N, nh*64), dqkv like qkv; lse2 f32 (S, nh, hp*32)."""
+    _need_gpu(qkv, rel_cat, out, lse2, scratch)
+    lib = N.load()
+    with torch.cuda.device(qkv.device):
+        N.check(lib.bsg_op_attention(_stream(), which, S, nh, hp, wp, _ptr(qkv), _ptr(rel_cat), _ptr(rel_catT), _ptr(dout),
+                                     _ptr(out), _ptr(lse2), _ptr(dqkv), _ptr(scratch), scratch.numel()))

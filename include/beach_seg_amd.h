@@ -156,6 +156,16 @@ int bsg_tile_frontend(void* stream, const uint8_t* mosaic, int mh, int mw, int n
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,
                 void* out);
 
+/* The fused attention kernels on their own (unit tests and micro-benchmarks), bf16: qkv T[S*N][3*nh*64] (q | k | v column
+ * blocks, head h at columns h*64), N = hp*wp tokens per stream; rel_cat / rel_catT as in the weight table (slots 18 / 19);
+ * `which` bit 0: forward -> out T[S*N][nh*64], lse2 f32[S][nh][hp*32]; bit 1: dQ (needs out, lse2 of a forward and dout
+ * T[S*N][nh*64]) -> dqkv q columns; bit 2: dK, dV (needs the tables a dQ launch left in `scratch`) -> dqkv k, v columns.
+ * scratch: >= bsg_op_attention_scratch_bytes bytes. */
+size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp);
+int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
+                     const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
+                     size_t scratch_bytes);
+
 /* Optional per-launch timing (HIP events recorded on the caller's stream around the kernels of one category):
  * 0 GEMM, 1 attention fwd, 2 attention bwd dQ, 3 attention bwd dK/dV, 4 3x3 conv.  bsg_profile_read waits for the
  * recorded events and returns the summed kernel time, the summed ALGORITHMIC flops and the launch count since
