@@ -15,6 +15,7 @@
 #include <algorithm>
 #include "attention.hpp"
 #include "decoder.hpp"
+#include "frontend.hpp"
 #include "gemm.hpp"
 #include "loss.hpp"
 #include "rowops.hpp"
@@ -840,6 +841,59 @@ int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, con
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true>), dim3(((hp + 7) / 8) * nh * S), dim3(512), lds_kv, st, k);
     CHECK_LAUNCH();
   }
+  return 0;
+}
+
+int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* bands, const uint8_t* nodata, uint8_t* out_rgb,
+                  void* scratch) {
+  if (!bands || !out_rgb || !scratch) return fail("bsg_tif_image: null argument");
+  if (C != 4 && C != 8) return fail("bsg_tif_image: expected 4 or 8 bands, got %d", C);
+  if (in_dtype != 0 && in_dtype != 1) return fail("bsg_tif_image: in_dtype must be 0 (f32) or 1 (u16)");
+  if (H <= 0 || W <= 0) return fail("bsg_tif_image: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  TifArgs a{};
+  a.bands = bands; a.nodata = nodata; a.keys = (int*)scratch; a.out = out_rgb; a.dtype = in_dtype; a.C = C; a.hw = (long)H * W;
+  const unsigned grid = (unsigned)std::min<long>((a.hw + 255) / 256, 2048);
+  hipLaunchKernelGGL(tif_init_kernel, dim3(1), dim3(64), 0, st, a.keys);
+  hipLaunchKernelGGL(tif_min_kernel, dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(tif_max_kernel, dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(tif_map_kernel, dim3(grid), dim3(256), 0, st, a);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_train_aug(void* stream, int batch, int h, int w, const float* img, const uint8_t* mask, const int32_t* params,
+                  const float* noise, const float mean[3], const float std[3], float* out, uint8_t* mask_out) {
+  if (!img || !params || !out) return fail("bsg_train_aug: null argument");
+  if ((mask == nullptr) != (mask_out == nullptr)) return fail("bsg_train_aug: mask and mask_out go together");
+  AugArgs a{};
+  a.img = img; a.mask = mask; a.params = (const int*)params; a.noise = noise; a.out = out; a.mask_out = mask_out;
+  a.B = batch; a.H = h; a.W = w;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.istd[c] = 1.f / std[c]; }
+  const long n = (long)batch * h * w;
+  hipLaunchKernelGGL(train_aug_fwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)stream, a);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const int32_t* params, const float std[3],
+                      float* grad_img) {
+  if (!grad_out || !params || !grad_img) return fail("bsg_train_aug_bwd: null argument");
+  const long n = (long)batch * h * w;
+  hipLaunchKernelGGL(train_aug_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, (const int*)params, grad_img, batch, h, w, 1.f / std[0], 1.f / std[1], 1.f / std[2]);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_confusion_update(void* stream, long n, int K, int ignore_index, const int64_t* pred_i64, const uint8_t* pred_u8,
+                         const uint8_t* target, uint64_t* confmat) {
+  if ((!pred_i64 && !pred_u8) || !target || !confmat) return fail("bsg_confusion_update: null argument");
+  if (K <= 0 || K > 16) return fail("bsg_confusion_update: K must be in 1..16");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)pred_i64, pred_u8, target, n, K, ignore_index, (unsigned long long*)confmat);
+  CHECK_LAUNCH();
   return 0;
 }
 

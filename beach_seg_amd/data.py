@@ -18,36 +18,92 @@ from .config import BeachSegConfig
 
 
 def tif_image(bands: np.ndarray, nodata: np.ndarray | None = None) -> np.ndarray:
-    """4-band (B,G,R,NIR) or 8-band surface-reflectance raster (C,H,W) -> uint8 (H,W,3), as
-    `src/util/geo_util.py:449-470` (4 bands: R = band 4, G = band 3, B = mean(band 1, band 2); clip to
-    [min, min+3000] over the valid pixels; per-channel divide by the max; nodata -> 0; truncating x255) and
-    `src/util/multichannel_img.py:7-29` (8 bands: log10 of band-group means, per-channel min/max stretch).
-    The reference's in-place true-divide needs a floating raster; integer rasters are promoted to float32 here."""
-    data = np.asarray(bands)
-    if not np.issubdtype(data.dtype, np.floating):
-        data = data.astype(np.float32)
-    nodata = np.zeros(data.shape[1:], dtype=bool) if nodata is None else np.asarray(nodata, dtype=bool)
-    if data.shape[0] == 8:
-        red, green, blue = np.mean(data[5:], axis=0), np.mean(data[2:5], axis=0), np.mean(data[:2], axis=0)
-        img = np.dstack((np.log10(1.0 + red), np.log10(1.0 + green), np.log10(1.0 + blue)))
-        img -= np.array([img[:, :, i][~nodata].min() for i in range(3)])
-        img /= img.max(axis=(0, 1))
-        img[nodata] = 0.0
-    elif data.shape[0] == 4:
-        img = np.zeros((3, *data.shape[1:]), dtype=data.dtype)
-        img[0] = data[3]
-        img[1] = data[2]
-        img[2] = data[:2].mean(axis=0)
-        min_val = img[:, ~nodata].min()
-        img = img.clip(min_val, 3000 + min_val) - min_val
-        img -= img[:, ~nodata].min()
-        for i in range(3):
-            img[i] /= img[i].max()
-            img[i][nodata] = 0
-        img = img.transpose((1, 2, 0)).copy()
+    """4-band (B,G,R,NIR) or 8-band surface-reflectance raster (C,H,W) -> uint8 (H,W,3): the display image of
+    `src/util/geo_util.py:449-470` / `src/util/multichannel_img.py:7-29`, written channel-vectorised.
+      4 bands: channels (band 4, band 3, mean(band 1, band 2)); ONE floor = their minimum over the valid pixels; values
+               clipped to [floor, floor + 3000] and shifted to 0; each channel divided by its own maximum.
+      8 bands: log10(1 + mean) of the band groups (6-8, 3-5, 1-2); each channel shifted by its minimum over the valid
+               pixels and divided by its maximum.
+    nodata pixels come out 0; the float image is truncated to uint8 after x255.  The reference reads rasters as float32
+    (`geo_util.py:385`); integer rasters are promoted to float32.  Host twin of `ops.tif_image` (the device kernel)."""
+    x = np.asarray(bands)
+    if not np.issubdtype(x.dtype, np.floating):
+        x = x.astype(np.float32)
+    hole = np.zeros(x.shape[1:], dtype=bool) if nodata is None else np.asarray(nodata, dtype=bool)
+    seen = ~hole
+    if x.shape[0] == 4:
+        ch = np.stack((x[3], x[2], x[:2].mean(axis=0)))                       # (3,H,W)
+        floor = ch[:, seen].min()
+        ch = np.clip(ch, floor, 3000 + floor) - floor
+        ch = ch - ch[:, seen].min()                                             # exact +0 whenever a valid pixel exists
+    elif x.shape[0] == 8:
+        ch = np.stack([np.log10(1.0 + grp.mean(axis=0)) for grp in (x[5:], x[2:5], x[:2])])
+        ch = ch - ch[:, seen].min(axis=1)[:, None, None]
     else:
-        raise ValueError(f"expected 4 or 8 bands, got {data.shape[0]}")
-    return np.array(img * 255, dtype=np.uint8)
+        raise ValueError(f"expected 4 or 8 bands, got {x.shape[0]}")
+    ch = ch / ch.max(axis=(1, 2), keepdims=True)
+    ch[:, hole] = 0
+    return (np.moveaxis(ch, 0, -1) * 255).astype(np.uint8)
+
+
+def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, generator: torch.Generator | None = None
+                            ) -> tuple[torch.Tensor, torch.Tensor | None]:
+    """Random parameters of the train-time augmentation chain (`src/data.py:195-224`), drawn on the host from an explicit
+    generator (kornia draws them internally; kornia is not installable here, so the DISTRIBUTIONS follow kornia's
+    documented parameter generators and the draw order is this function's own: "parity unpinned"):
+      vertical / horizontal flip ~ Bernoulli(p);  erasing ~ Bernoulli(erasing_p) with area fraction ~ U(erasing_scale),
+      log-uniform aspect ratio in (0.3, 3.3), box placed uniformly inside the image;  noise ~ Bernoulli(gauss_p).
+    Returns (params i32 (B,5) = [flags, ex0, ey0, ew, eh], noise f32 (B,3,h,w) or None)."""
+    import math
+
+    g = generator
+    u = lambda *s: torch.rand(*s, generator=g)
+    flags = (u(batch) < config.vertical_flip).int() | ((u(batch) < config.horizontal_flip).int() << 1)
+    do_noise = u(batch) < config.gauss_p
+    flags |= do_noise.int() << 2
+    erase = u(batch) < config.erasing_p
+    area = (config.erasing_scale[0] + u(batch) * (config.erasing_scale[1] - config.erasing_scale[0])) * h * w
+    ratio = torch.exp(math.log(0.3) + u(batch) * (math.log(3.3) - math.log(0.3)))
+    ew = torch.sqrt(area * ratio).round().clamp(1, w).int()
+    eh = torch.sqrt(area / ratio).round().clamp(1, h).int()
+    ex = (u(batch) * (w - ew + 1).float()).floor().int()
+    ey = (u(batch) * (h - eh + 1).float()).floor().int()
+    zero = torch.zeros_like(ew)
+    params = torch.stack([flags, torch.where(erase, ex, zero), torch.where(erase, ey, zero), torch.where(erase, ew, zero),
+                          torch.where(erase, eh, zero)], dim=1).to(torch.int32).contiguous()
+    noise = None
+    if bool(do_noise.any()):
+        noise = torch.randn(batch, 3, h, w, generator=g) * config.gauss_std + config.gauss_mean
+    return params, noise
+
+
+def train_aug_reference(img: torch.Tensor, mask: torch.Tensor | None, params: torch.Tensor, noise: torch.Tensor | None,
+                        mean=ml_util.IMAGE_MEAN, std=ml_util.IMAGE_STD):
+    """Plain-torch statement of what `ops.train_aug` computes (any device, autograd through torch): the test oracle of the
+    HIP kernel and the CPU fallback-free documentation of its semantics."""
+    out, mout = [], []
+    for b in range(img.shape[0]):
+        fl, ex, ey, ew, eh = (int(v) for v in params[b])
+        x = img[b]
+        m = mask[b] if mask is not None else None
+        if fl & 1:
+            x = x.flip(-2)
+            m = m.flip(-2) if m is not None else None
+        if fl & 2:
+            x = x.flip(-1)
+            m = m.flip(-1) if m is not None else None
+        if ew > 0 and eh > 0:
+            keep = torch.ones_like(x[0])
+            keep[ey:ey + eh, ex:ex + ew] = 0
+            x = x * keep
+        if fl & 4 and noise is not None:
+            x = x + noise[b].to(x.device)
+        out.append(x)
+        mout.append(m)
+    out = torch.stack(out)
+    mean_t = torch.tensor(mean, dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
+    std_t = torch.tensor(std, dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
+    return (out - mean_t) / std_t, (torch.stack(mout) if mask is not None else None)
 
 
 def pil_bicubic_tables(in_size: int, out_size: int) -> tuple[np.ndarray, np.ndarray]:
@@ -151,6 +207,11 @@ def synthetic_dove_scene(seed: int = 1234, size: int = 256, n_dates: int = 1) ->
     return imgs, masks
 
 
+def synthetic_dove_bands(seed: int = 1234, size: int = 256) -> np.ndarray:
+    """The raw uint16 (4, size, size) tile of `synthetic_dove_scene` (first date): the device front-end's input."""
+    return np.random.default_rng(seed).integers(200, 3200, size=(4, size, size), dtype=np.uint16)
+
+
 class BeachSegDataModule:
     """The attributes `PromptModel` / the drivers read from `src/data.py:181-346`."""
 
@@ -159,6 +220,7 @@ class BeachSegDataModule:
         self.config = config
         self.mean, self.std = ml_util.IMAGE_MEAN, ml_util.IMAGE_STD
         self.normalize, self.denormalize = ml_util.normalize, ml_util.denormalize
+        self.aug_generator = torch.Generator().manual_seed(config.seed + 2)
         self.scene = scene or synthetic_dove_scene()
         size = next(iter(self.scene[0].values()))[0].shape[0]
         cs = config.crop_size
@@ -169,7 +231,23 @@ class BeachSegDataModule:
         out["image"] = self.normalize(batch["image"])
         return out
 
-    train_aug = aug  # kornia's random flips / colour jitter / erasing / noise: SURVEY.md section 8 f-4 ("next")
+    def train_aug(self, batch: dict) -> dict:
+        """`src/data.py:195-224` on the batch dict: flips (image and mask together), RandomErasing, Gaussian noise,
+        Normalize, on device with backward to `batch["image"]` (`ops.train_aug`).  ColorJiggle / RandomSharpness are
+        not built (kornia-internal formulas: "parity unpinned").  Random parameters come from `self.aug_generator`."""
+        from . import ops
+
+        img = batch["image"]
+        B, _, h, w = img.shape
+        params, noise = sample_train_aug_params(B, h, w, self.config, self.aug_generator)
+        mask = batch.get("mask")
+        out, mo = ops.train_aug(img, mask, params.to(img.device), noise.to(img.device) if noise is not None else None,
+                                self.mean, self.std)
+        res = dict(batch)
+        res["image"] = out
+        if mo is not None:
+            res["mask"] = mo
+        return res
 
     def setup(self, stage: str) -> None:
         imgs, masks = self.scene

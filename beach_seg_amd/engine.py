@@ -44,6 +44,24 @@ def broadcast_from_rank0(t: torch.Tensor, process_group=None) -> None:
         dist.broadcast(t, src=0, group=process_group)
 
 
+def reduce_metrics(loss_sum: torch.Tensor, n_steps: int, confmat: torch.Tensor, process_group=None
+                   ) -> tuple[torch.Tensor, torch.Tensor]:
+    """The second, tiny collective of SURVEY.md section 8(e): what Lightning's `sync_dist=True` does for the logged loss and
+    the torchmetrics state (`src/model.py:316, 327`).  One SUM all-reduce of [loss sum, step count, K*K confusion counts]
+    (float64: exact for counts < 2^53) -> (mean loss over all ranks' steps, global confusion matrix)."""
+    K = confmat.shape[0]
+    buf = torch.cat([loss_sum.detach().double().reshape(1), torch.tensor([float(n_steps)], dtype=torch.float64, device=loss_sum.device),
+                     confmat.double().flatten()])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        if buf.is_cuda and dist.get_backend(process_group) == "gloo":
+            h = buf.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=process_group)
+            buf.copy_(h)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+    return buf[0] / buf[1].clamp_min(1), buf[2:].round().long().reshape(K, K)
+
+
 def shard_batch(global_batch: int, rank: int, world: int) -> range:
     """Contiguous slice of the global batch owned by `rank` (SURVEY.md section 8 e)."""
     if global_batch % world:

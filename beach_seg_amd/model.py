@@ -31,35 +31,54 @@ class SegGptLoss(torch.nn.Module):
 
 
 class MulticlassF1:
-    """Macro F1 over the non-ignored classes from tp/fp/fn counts (stand-in for
-    `torchmetrics.MulticlassF1Score(num_classes, ignore_index=0)`, `src/model.py:85-93`; torchmetrics is not
-    installed here, so this metric is "parity unpinned")."""
+    """`torchmetrics.MulticlassF1Score(num_classes, ignore_index=0)` (macro average; `src/model.py:85-93`).  State = the
+    (K, K) confusion matrix over the pixels whose target is not ignored, updated by ONE HIP kernel per call
+    (`bsg_confusion_update`, no host synchronisation); it is what `sync_dist=True` sums over ranks
+    (`src/model.py:316, 327`; `engine.reduce_metrics`).  `compute` restates torchmetrics 1.x (`_multiclass_stat_scores_
+    update` + `_fbeta_reduce` / `_adjust_weights_safe_divide`): tp = diag, fp = column sums - tp, fn = row sums - tp,
+    F1_c = 2 tp / (2 tp + fp + fn) with 0/0 := 0, macro mean over the classes with tp + fp + fn > 0.  torchmetrics is not
+    installed here, so the metric is "parity unpinned" beyond this restatement."""
 
-    def __init__(self, num_classes: int, ignore_index: int = 0, device="cpu"):
+    def __init__(self, num_classes: int, ignore_index: int | None = 0, device="cpu"):
         self.n, self.ignore = num_classes, ignore_index
-        self.tp = torch.zeros(num_classes, dtype=torch.long, device=device)
-        self.fp = torch.zeros_like(self.tp)
-        self.fn = torch.zeros_like(self.tp)
+        self.confmat = torch.zeros(num_classes, num_classes, dtype=torch.int64, device=device)
 
     def update(self, pred: torch.Tensor, target: torch.Tensor) -> None:
-        keep = target != self.ignore
-        p, t = pred[keep].long(), target[keep].long()
-        for c in range(self.n):
-            self.tp[c] += ((p == c) & (t == c)).sum()
-            self.fp[c] += ((p == c) & (t != c)).sum()
-            self.fn[c] += ((p != c) & (t == c)).sum()
+        if self.confmat.is_cuda:
+            ops.confusion_update(self.confmat, pred, target, self.ignore)
+        else:  # host tensors (CPU unit tests of the formula): the same counts with bincount
+            t, p = target.flatten().long(), pred.flatten().long()
+            if self.ignore is not None:
+                keep = t != self.ignore
+                t, p = t[keep], p[keep]
+            self.confmat += torch.bincount(t * self.n + p, minlength=self.n * self.n).reshape(self.n, self.n)
 
-    def state(self) -> torch.Tensor:  # (3, n) counts: what `sync_dist=True` all-reduces (src/model.py:316, 327)
-        return torch.stack([self.tp, self.fp, self.fn])
+    def state(self) -> torch.Tensor:
+        return self.confmat
+
+    @property
+    def tp(self):
+        return self.confmat.diag()
+
+    @property
+    def fp(self):
+        return self.confmat.sum(0) - self.confmat.diag()
+
+    @property
+    def fn(self):
+        return self.confmat.sum(1) - self.confmat.diag()
 
     def compute(self, state: torch.Tensor | None = None) -> float:
-        tp, fp, fn = (state if state is not None else self.state()).double()
-        f1 = 2 * tp / (2 * tp + fp + fn).clamp_min(1)
-        cls = [c for c in range(self.n) if c != self.ignore]
-        return float(f1[cls].mean())
+        cm = (state if state is not None else self.confmat).double()
+        tp = cm.diag()
+        fp, fn = cm.sum(0) - tp, cm.sum(1) - tp
+        den = 2 * tp + fp + fn
+        f1 = torch.where(den > 0, 2 * tp / den.clamp_min(1), torch.zeros_like(den))
+        w = ((tp + fp + fn) > 0).double()
+        return float((w * f1).sum() / w.sum()) if float(w.sum()) > 0 else 0.0
 
     def reset(self) -> None:
-        self.tp.zero_(); self.fp.zero_(); self.fn.zero_()
+        self.confmat.zero_()
 
 
 def lr_at_epoch(conf: BeachSegConfig, epoch: int) -> float:
@@ -89,7 +108,14 @@ class PromptModel(torch.nn.Module):
         self.palette_g = torch.Generator(device="cpu").manual_seed(conf.seed + 1)
         self.loss_fn = SegGptLoss(conf.loss_beta, conf.loss_variant)
         self.normalize, self.denormalize = ml_util.normalize, ml_util.denormalize
+        self.train_aug = self.aug = None  # set by post_init (src/model.py:104-108); None = Normalize only
         self.current_epoch = 0
+        self._prompt_stack = None
+
+    # ---- src/model.py:104-113
+    def post_init(self, datamodule) -> None:
+        self.train_aug, self.aug = datamodule.train_aug, datamodule.aug
+        self.normalize, self.denormalize = datamodule.normalize, datamodule.denormalize
 
     @property
     def device(self) -> torch.device:
@@ -124,10 +150,21 @@ class PromptModel(torch.nn.Module):
     def prepare_prompt(self, batch_idxes, batch_palette: torch.Tensor, train: bool):
         idx = batch_idxes.flatten().tolist() if isinstance(batch_idxes, torch.Tensor) else (
             [batch_idxes] if isinstance(batch_idxes, int) else list(batch_idxes))
-        image = torch.stack([self.prompt_batch["image"][i] for i in idx], dim=0)  # autograd-tracked stack
-        mask = self.prompt_batch["mask"][torch.tensor(idx, device=self.device)]
-        prompt_batch = {"image": self.normalize(image), "mask": mask,
-                        "crop_idx": self.prompt_batch["crop_idx"][torch.tensor(idx)]}
+        sel = torch.tensor(idx, device=self.device)
+        if torch.is_grad_enabled():
+            image = torch.stack([self.prompt_batch["image"][i] for i in idx], dim=0)  # autograd-tracked stack
+        else:  # inference (predict loop): one gather from a cached stack instead of B Parameter reads
+            if self._prompt_stack is None or self._prompt_stack[0] is not self.prompt_batch["image"]:
+                self._prompt_stack = (self.prompt_batch["image"], torch.stack([p.detach() for p in self.prompt_batch["image"]]))
+            image = self._prompt_stack[1].index_select(0, sel)
+        mask = self.prompt_batch["mask"][sel]
+        aug = self.train_aug if train else self.aug
+        if aug is not None:  # src/model.py:204-207: flips / erasing / noise / Normalize (train) or Normalize (eval)
+            out = aug({"image": image, "mask": mask})
+            image_n, mask = out["image"], out["mask"]
+        else:
+            image_n = self.normalize(image)
+        prompt_batch = {"image": image_n, "mask": mask, "crop_idx": self.prompt_batch["crop_idx"][torch.tensor(idx)]}
         prompt_color = self.normalize(ml_util.torch_apply_mask_rgb(batch_palette, mask))
         return prompt_batch, prompt_color
 

@@ -252,3 +252,89 @@ def attention(which: int, qkv: torch.Tensor, rel_cat: torch.Tensor, S: int, nh: 
     with torch.cuda.device(qkv.device):
         N.check(lib.bsg_op_attention(_stream(), which, S, nh, hp, wp, _ptr(qkv), _ptr(rel_cat), _ptr(rel_catT), _ptr(dout),
                                      _ptr(out), _ptr(lse2), _ptr(dqkv), _ptr(scratch), scratch.numel()))
+
+
+def tif_image(bands: torch.Tensor, nodata: torch.Tensor | None = None) -> torch.Tensor:
+    """Device `tif_image` (`src/util/geo_util.py:449-470`): bands f32 or u16 (C,H,W), C in {4, 8}; nodata bool/u8 (H,W) or
+    None -> u8 (H,W,3), the mosaic `tile_frontend` consumes.  4 bands: bit-exact against the reference's own output."""
+    _need_gpu(bands, nodata)
+    if bands.dim() != 3 or bands.shape[0] not in (4, 8):
+        raise ValueError(f"expected a (4|8, H, W) raster, got {tuple(bands.shape)}")
+    if bands.dtype == torch.float32:
+        dt = 0
+    elif bands.dtype == torch.uint16:
+        dt = 1
+    else:
+        raise ValueError("bands must be float32 (what the reference reads) or uint16")
+    lib = N.load()
+    Cb, H, W = bands.shape
+    nd = nodata.to(torch.uint8).contiguous() if nodata is not None else None
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=bands.device)
+    scratch = torch.empty(32, dtype=torch.uint8, device=bands.device)
+    with torch.cuda.device(bands.device):
+        N.check(lib.bsg_tif_image(_stream(), Cb, H, W, dt, _ptr(bands.contiguous()), _ptr(nd), _ptr(out), _ptr(scratch)))
+    return out
+
+
+class _TrainAugFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, mask, params, noise, mean, std):
+        lib = N.load()
+        B, _, h, w = img.shape
+        img_c = img.detach().float().contiguous()
+        out = torch.empty_like(img_c)
+        mask_c = mask.to(torch.uint8).contiguous() if mask is not None else None
+        mask_out = torch.empty_like(mask_c) if mask_c is not None else None
+        with torch.cuda.device(img.device):
+            N.check(lib.bsg_train_aug(_stream(), B, h, w, _ptr(img_c), _ptr(mask_c), _ptr(params), _ptr(noise), _f3(mean),
+                                      _f3(std), _ptr(out), _ptr(mask_out)))
+        ctx.params, ctx.std, ctx.shape = params, std, (B, h, w)
+        ctx.mark_non_differentiable(*([mask_out] if mask_out is not None else []))
+        return (out, mask_out) if mask_out is not None else (out, None)
+
+    @staticmethod
+    def backward(ctx, gout, _gmask=None):
+        lib = N.load()
+        B, h, w = ctx.shape
+        g = gout.contiguous().float()
+        gin = torch.empty_like(g)
+        with torch.cuda.device(g.device):
+            N.check(lib.bsg_train_aug_bwd(_stream(), B, h, w, _ptr(g), _ptr(ctx.params), _f3(ctx.std), _ptr(gin)))
+        return gin, None, None, None, None, None
+
+
+def train_aug(img: torch.Tensor, mask: torch.Tensor | None, params: torch.Tensor, noise: torch.Tensor | None = None,
+              mean=IMAGE_MEAN, std=IMAGE_STD):
+    """The train-time augmentation chain of `src/data.py:195-224` with explicit random parameters (`bsg_train_aug`):
+    img f32 (B,3,h,w) in [0,1] (autograd-tracked: the stacked prompt Parameters), mask u8 (B,h,w) / (B,1,h,w) or None,
+    params i32 (B,5) from `data.sample_train_aug_params`, noise f32 (B,3,h,w) or None -> (normalised image, mask)."""
+    _need_gpu(img, mask, params, noise)
+    if params.dtype != torch.int32 or tuple(params.shape) != (img.shape[0], 5):
+        raise ValueError("params must be int32 (B, 5)")
+    m = mask
+    if m is not None and m.dim() == 4:
+        m = m[:, 0]
+    out, mo = _TrainAugFn.apply(img, m, params.contiguous(), noise.contiguous() if noise is not None else None, tuple(mean),
+                                tuple(std))
+    if mo is not None and mask.dim() == 4:
+        mo = mo[:, None]
+    return out, mo
+
+
+def confusion_update(confmat: torch.Tensor, pred: torch.Tensor, target: torch.Tensor, ignore_index: int | None) -> None:
+    """confmat i64 (K,K) += counts of (target, pred) pairs with target != ignore_index: one kernel, no host sync
+    (`MulticlassF1Score.update`, `src/model.py:256, 295`)."""
+    _need_gpu(confmat, pred, target)
+    if confmat.dtype != torch.int64 or confmat.dim() != 2 or confmat.shape[0] != confmat.shape[1]:
+        raise ValueError("confmat must be int64 (K, K)")
+    lib = N.load()
+    t = target.to(torch.uint8).contiguous()
+    p = pred.contiguous()
+    if p.dtype not in (torch.int64, torch.uint8):
+        p = p.to(torch.int64)
+    if p.numel() != t.numel():
+        raise ValueError("pred and target must have the same number of pixels")
+    with torch.cuda.device(confmat.device):
+        N.check(lib.bsg_confusion_update(_stream(), t.numel(), confmat.shape[0], -1 if ignore_index is None else ignore_index,
+                                         _ptr(p) if p.dtype == torch.int64 else None,
+                                         _ptr(p) if p.dtype == torch.uint8 else None, _ptr(t), _ptr(confmat)))

@@ -151,6 +151,32 @@ int bsg_tile_frontend(void* stream, const uint8_t* mosaic, int mh, int mw, int n
                       int S, const int32_t* coef, const int32_t* bounds, int kmax, const float* mean3,
                       const float* std3, float* out, uint8_t* out_u8);
 
+/* `tif_image` (src/util/geo_util.py:449-470; 8 bands: src/util/multichannel_img.py:7-29) on device: bands (C,H,W) f32
+ * (in_dtype 0, what the reference reads with out_dtype=float32, geo_util.py:385) or u16 (in_dtype 1, promoted exactly),
+ * nodata u8 (H,W) or NULL -> out_rgb u8 (H,W,3), the mosaic format bsg_tile_frontend consumes.  C = 4: R = band 4, G =
+ * band 3, B = mean(band 1, band 2), clip to [min, min + 3000] over the valid pixels, per-channel divide by the max,
+ * nodata -> 0, truncating x255 -- bit-exact against the reference's own output; C = 8: log10(1 + band-group mean), per-
+ * channel min / max stretch.  scratch: >= 32 bytes of device memory, contents irrelevant. */
+int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* bands, const uint8_t* nodata,
+                  uint8_t* out_rgb, void* scratch);
+
+/* Train-time augmentation of src/data.py:195-224 with EXPLICIT random parameters (the reference draws them inside
+ * kornia): per sample params[b] = {flags, ex0, ey0, ew, eh}, flags bit 0 = vertical flip, bit 1 = horizontal flip, bit 2 =
+ * add `noise` (f32 (B,3,h,w), already scaled by gauss_std and shifted by gauss_mean), the e* box is erased to 0 (ew = 0:
+ * none); order flips -> erase -> noise -> Normalize.  ColorJiggle / RandomSharpness are not built.  img f32 (B,3,h,w) in
+ * [0,1] -> out; mask u8 (B,h,w) -> mask_out follows the flips only (both NULL to skip).  bsg_train_aug_bwd is the
+ * gradient wrt img (the learnable prompt pixels, src/model.py:197-205). */
+int bsg_train_aug(void* stream, int batch, int h, int w, const float* img, const uint8_t* mask, const int32_t* params,
+                  const float* noise, const float mean[3], const float std[3], float* out, uint8_t* mask_out);
+int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const int32_t* params,
+                      const float std[3], float* grad_img);
+
+/* State update of MulticlassF1Score(num_classes=K, ignore_index) (src/model.py:85-93, 256, 295): confmat[t][p] += 1 over
+ * the n pixels whose target t != ignore_index (pass -1 for none); confmat u64 [K][K], K <= 16; pred as i64 or u8 (the
+ * other NULL).  tp / fp / fn are the diagonal / column sums / row sums; the matrix is what ranks all-reduce (SUM). */
+int bsg_confusion_update(void* stream, long n, int K, int ignore_index, const int64_t* pred_i64, const uint8_t* pred_u8,
+                         const uint8_t* target, uint64_t* confmat);
+
 /* The NT GEMM kernel on its own (unit tests and micro-benchmarks): out[M][N] = A[M][K] W[N][K]^T (+ bias[N]),
  * A / W / out in the dtype given (0 f32, 1 bf16), bias f32 or NULL. */
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,

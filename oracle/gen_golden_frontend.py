@@ -50,11 +50,17 @@ bands[:, 5:9, 7:30] += 4000.0                                          # bright 
 nodata = np.zeros((48, 40), dtype=bool)
 nodata[40:, :6] = True
 tif_rgb = ref_geo.tif_image(bands.copy(), nodata)
+# 8-band (SuperDove) branch: src/util/multichannel_img.py:7-29 through the same entry point
+bands8 = rng.uniform(150, 4200, size=(8, 40, 56)).astype(np.float32)
+nodata8 = np.zeros((40, 56), dtype=bool)
+nodata8[:5, 50:] = True
+tif8_rgb = ref_geo.tif_image(bands8.copy(), nodata8)
 pc_src = np.arange(7 * 9 * 3, dtype=np.uint8).reshape(7, 9, 3)
 pc_boxes = np.array([[-2, -1, 3, 4], [6, 4, 11, 9], [2, 1, 7, 6]], dtype=np.int32)
 pc_out = np.stack([ref_geo.padded_crop(pc_src, int(b[0]), int(b[1]), int(b[2]), int(b[3]), 5, 0) for b in pc_boxes])
 
 np.savez_compressed(root / "tests" / "golden" / "frontend_pil.npz", tif_bands=bands, tif_nodata=nodata, tif_rgb=tif_rgb,
+                    tif8_bands=bands8, tif8_nodata=nodata8, tif8_rgb=tif8_rgb,
                     pc_src=pc_src, pc_boxes=pc_boxes, pc_out=pc_out, mosaic=mosaic, boxes112=boxes, out112=out112,
                     boxes256=boxes256, out256=out256, down256_96=down, pil_version=np.array(Image.__version__))
 print("wrote frontend_pil.npz", out112.shape, out256.shape, down.shape, Image.__version__)

@@ -84,6 +84,60 @@ def test_f1_counts():
     assert abs(m.compute() - (1.0 + 2 / 3 + 2 / 3) / 3) < 1e-9
 
 
+def test_f1_macro_average_follows_torchmetrics_rules():
+    """ignore_index drops the ignored TARGETS only: predicting the ignored class on a valid pixel is a false positive of
+    that class, which then takes part in the macro mean with F1 = 0 (torchmetrics `_adjust_weights_safe_divide`: a class
+    is left out only when tp + fp + fn == 0)."""
+    m = MulticlassF1(4, ignore_index=0)
+    m.update(torch.tensor([0, 2, 2, 3]), torch.tensor([1, 2, 3, 3]))
+    assert m.confmat.tolist() == [[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 1, 1]]
+    # class 0: fp 1 -> F1 0 (counted); class 1: fn 1 -> 0; class 2: tp 1 fp 1 -> 2/3; class 3: tp 1 fn 1 -> 2/3
+    assert abs(m.compute() - (0 + 0 + 2 / 3 + 2 / 3) / 4) < 1e-12
+    m2 = MulticlassF1(4, ignore_index=None)
+    m2.update(torch.tensor([0, 2]), torch.tensor([0, 2]))
+    assert abs(m2.compute() - 1.0) < 1e-12  # classes 1 and 3 never appear: weight 0
+    m.reset()
+    assert int(m.confmat.sum()) == 0 and m.compute() == 0.0
+
+
+def test_train_aug_parameters_and_reference_semantics():
+    from beach_seg_amd.data import sample_train_aug_params, train_aug_reference
+
+    conf = BeachSegConfig(vertical_flip=0.5, horizontal_flip=0.5, erasing_p=0.6, gauss_p=0.5)
+    g = torch.Generator().manual_seed(3)
+    params, noise = sample_train_aug_params(16, 32, 48, conf, g)
+    p2, n2 = sample_train_aug_params(16, 32, 48, conf, torch.Generator().manual_seed(3))
+    assert torch.equal(params, p2) and torch.equal(noise, n2) and params.dtype == torch.int32 and params.shape == (16, 5)
+    fl, ex, ey, ew, eh = params.unbind(1)
+    assert int(fl.min()) >= 0 and int(fl.max()) <= 7 and 0 < int((fl & 1).sum()) < 16 and 0 < int(((fl >> 1) & 1).sum()) < 16
+    on = ew > 0
+    assert 0 < int(on.sum()) < 16 and bool(((ex + ew)[on] <= 48).all()) and bool(((ey + eh)[on] <= 32).all())
+    area = (ew * eh)[on].float() / (32 * 48)
+    assert float(area.min()) > 0.01 and float(area.max()) < 0.08  # erasing_scale (0.02, 0.05) up to rounding
+    # semantics + gradient of the reference statement: flips undo themselves, the erased box gets no gradient
+    img = torch.rand(2, 3, 8, 10, requires_grad=True)
+    mask = torch.randint(0, 4, (2, 8, 10), dtype=torch.uint8)
+    prm = torch.tensor([[1 | 4, 2, 1, 3, 2], [2, 0, 0, 0, 0]], dtype=torch.int32)
+    nz = torch.randn(2, 3, 8, 10) * 0.1
+    out, mo = train_aug_reference(img, mask, prm, nz)
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(3, 1, 1); std = torch.tensor((0.229, 0.224, 0.225)).view(3, 1, 1)
+    x0 = img[0].detach().flip(-2).clone(); x0[:, 1:3, 2:5] = 0
+    assert torch.allclose(out[0], (x0 + nz[0] - mean) / std, atol=1e-6) and torch.equal(mo[0], mask[0].flip(-2))
+    assert torch.allclose(out[1], (img[1].detach().flip(-1) - mean) / std, atol=1e-6) and torch.equal(mo[1], mask[1].flip(-1))
+    out.sum().backward()
+    g0 = (torch.ones(3, 8, 10) / std); g0[:, 1:3, 2:5] = 0
+    assert torch.allclose(img.grad[0], g0.flip(-2)) and torch.allclose(img.grad[1], (torch.ones(3, 8, 10) / std))
+
+
+def test_tif_image_eight_band_and_uint16(golden_dir):
+    rec = np.load(golden_dir / "frontend_pil.npz")
+    assert np.array_equal(tif_image(rec["tif8_bands"], rec["tif8_nodata"]), rec["tif8_rgb"])  # reference's own output
+    u16 = np.random.default_rng(5).integers(200, 3200, size=(4, 20, 24), dtype=np.uint16)
+    assert np.array_equal(tif_image(u16), tif_image(u16.astype(np.float32)))
+    with pytest.raises(ValueError):
+        tif_image(np.zeros((5, 4, 4), np.float32))
+
+
 def test_shard_batch():
     assert list(shard_batch(8, 1, 4)) == [2, 3]
     with pytest.raises(ValueError):
@@ -100,6 +154,12 @@ def _dp_worker(rank, world, port, q):
         flat[r * n:(r + 1) * n] += (rank + 1) * (r + 1)
         flat[P * n + r] = 1.0
     reduce_prompt_grads(flat)
+    # the second, tiny collective: logged loss + F1 state (src/model.py:316, 327 sync_dist=True)
+    from beach_seg_amd.engine import reduce_metrics
+    cm = torch.zeros(4, 4, dtype=torch.int64)
+    cm[1, 1], cm[2, 3] = 3 + rank, 5
+    mean_loss, cm_all = reduce_metrics(torch.tensor(2.0 * (rank + 1)), 2, cm)
+    assert abs(float(mean_loss) - (2.0 + 4.0) / 4) < 1e-12 and cm_all[1, 1] == 7 and cm_all[2, 3] == 10 and int(cm_all.sum()) == 17
     q.put((rank, flat.clone()))
     dist.barrier()
     dist.destroy_process_group()
