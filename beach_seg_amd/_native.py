@@ -11,7 +11,7 @@ from pathlib import Path
 _LIB_PATH = Path(os.environ.get("BSG_LIB", Path(__file__).resolve().parent / "libbsg_hip.so"))  # BSG_LIB: experiments
 _lib = None
 
-BSG_DTYPE_F32, BSG_DTYPE_BF16 = 0, 1
+BSG_DTYPE_F32, BSG_DTYPE_BF16, BSG_DTYPE_F16 = 0, 1, 2
 BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 20
 
 # every exported symbol of include/beach_seg_amd.h (tests check the library exports exactly these)

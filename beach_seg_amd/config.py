@@ -28,7 +28,7 @@ class BeachSegConfig:
     world_size: int = 1
     grad_accum_steps: int = 1
     log_every_n_steps: int = 10
-    precision: str = "32-true"  # "32-true" -> fp32 parity kernels, "bf16-true" / "16-mixed" -> bf16 kernels
+    precision: str = "32-true"  # "32-true" -> exact-f32 kernels, "bf16-true" / "bf16-mixed" -> bf16, "16-true" / "16-mixed" -> IEEE half
     workers: int = -1
     batch_size: int = 1
 

@@ -106,11 +106,9 @@ template <typename T> DEVI typename Traits<T>::Chunk lds_chunk(const char* tile,
 // A-operand chunk of a [row][64 contraction slots] LDS tile matching an S^T-layout accumulator block used as
 // the B operand.  bf16: k-step s (16 slots) of 32-slot block b, element j <-> slot 16s + 8(j>>2) + 4h + (j&3);
 // f32: k-step s (8 slots), element j <-> slot 8s + 4h + j.  In both cases one conflict-free ds_read_b128.
-DEVI bf16x8 lds_perm_chunk(const char* tile, int row, int b, int s, int h, bf16_t) {
-  // bf16 "transposed" tensors are stored with every 16-slot group permuted (slot 8a + 4h + i at position
-  // 8h + 4a + i, see head_transpose_kernel), so the 8 slots a lane needs are ONE 16-byte chunk: 4b + 2s + h
-  const int c = 4 * b + 2 * s + h;
-  return *(const bf16x8*)(tile + row * 128 + ((c ^ swz<128>(row)) << 4));
+// (16-bit dtypes never take this path: their "transposed" operands come out of the row-major tiles, lds_tr_chunk)
+template <typename T16> DEVI typename Traits<T16>::Chunk lds_perm_chunk(const char*, int, int, int, int, T16) {
+  return typename Traits<T16>::Chunk{};
 }
 DEVI f32x4 lds_perm_chunk(const char* tile, int row, int b, int s, int h, float) {
   const int c = 8 * b + 2 * s + h;
@@ -121,21 +119,34 @@ DEVI f32x4 lds_perm_chunk(const char* tile, int row, int b, int s, int h, float)
 // columns 4p..4p+3) and hands lane i column i of the four rows.  Rows = slots 16s + 4h + {0..3} (+8 for the second
 // read), columns = d 32*db + 16*(group & 1) + i = this lane's A row.  No transposed copy in HBM, no permutation.
 typedef __attribute__((address_space(3))) bf16x4* lds_b4_ptr;
-DEVI bf16x8 lds_tr_chunk(const char* tile, int db, int b, int s, int lane) {
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4_raw* lds_h4_ptr;
+DEVI f32x2 lds_tr_read(const char* p, bf16_t) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)p));
+}
+DEVI f32x2 lds_tr_read(const char* p, f16_t) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)p));
+}
+template <typename T> DEVI typename Traits<T>::Chunk lds_tr_chunk(const char* tile, int db, int b, int s, int lane) {
   const int gi = lane >> 4, i = lane & 15, qd = i >> 2, p = i & 3, h = gi >> 1;
   const int r0 = 32 * b + 16 * s + 4 * h + qd;
   const int c = 4 * db + 2 * (gi & 1) + (p >> 1);
   const char* a0 = tile + r0 * 128 + ((c ^ swz<128>(r0)) << 4) + 8 * (p & 1);
   const char* a1 = tile + (r0 + 8) * 128 + ((c ^ swz<128>(r0 + 8)) << 4) + 8 * (p & 1);
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(a0));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(a1));
-  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  const f32x2 lo = lds_tr_read(a0, T()), hi = lds_tr_read(a1, T());
+  return __builtin_bit_cast(typename Traits<T>::Chunk, (f32x4{lo[0], lo[1], hi[0], hi[1]}));
 }
 // The matching B-operand chunk built from accumulator block `p` (already exponentiated / scaled).
 DEVI bf16x8 acc_chunk(const f32x16& p, int s, bf16_t) {
   bf16x8 c;
 #pragma unroll
   for (int j = 0; j < 8; ++j) c[j] = (bf16_t)p[8 * s + j];
+  return c;
+}
+DEVI f16x8 acc_chunk(const f32x16& p, int s, f16_t) {
+  f16x8 c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = (f16_t)p[8 * s + j];
   return c;
 }
 DEVI f32x4 acc_chunk(const f32x16& p, int s, float) { return f32x4{p[4 * s], p[4 * s + 1], p[4 * s + 2], p[4 * s + 3]}; }
@@ -291,7 +302,7 @@ template <typename T, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  static_assert(TR == (sizeof(T) == 2), "16-bit dtypes take the transposing-read path, f32 the transposed copies");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | VT (TR: V)][TILE]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const Chunk pb = acc_chunk(st[b], ks, T());
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          if constexpr (TR) mma32(o[db], lds_tr_chunk(vt_l, db, b, ks, lane), pb);
+          if constexpr (TR) mma32(o[db], lds_tr_chunk<T>(vt_l, db, b, ks, lane), pb);
           else mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
         }
       }
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #endif
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  static_assert(TR == (sizeof(T) == 2), "16-bit dtypes take the transposing-read path, f32 the transposed copies");
   constexpr int NTILE = TR ? 2 : 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [buf][K | V | KT (not TR)][TILE] | relh tables [4][32][HS]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
@@ -601,9 +612,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #if BSG_DIAG_DQ == 3
           if constexpr (TR) mma32(dqt[d], qf[(ks + d) & 3], db_);
 #elif BSG_DIAG_DQ == 2
-          if constexpr (TR) dqt[d][ks] += to_f32(lds_tr_chunk(k_l, d, b, ks, lane)[0]) * to_f32(db_[0]);
+          if constexpr (TR) dqt[d][ks] += to_f32(lds_tr_chunk<T>(k_l, d, b, ks, lane)[0]) * to_f32(db_[0]);
 #else
-          if constexpr (TR) mma32(dqt[d], lds_tr_chunk(k_l, d, b, ks, lane), db_);
+          if constexpr (TR) mma32(dqt[d], lds_tr_chunk<T>(k_l, d, b, ks, lane), db_);
 #endif
           else mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
         }
@@ -687,7 +698,7 @@ template <typename T, bool TR>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
-  static_assert(!TR || sizeof(T) == 2, "transposing LDS reads are the bf16 path");
+  static_assert(TR == (sizeof(T) == 2), "16-bit dtypes take the transposing-read path, f32 the transposed copies");
   constexpr int RB = C::RB, STAGE = DkvK<T, TR>::STAGE, NTILE = DkvK<T, TR>::NTILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
@@ -791,8 +802,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           if constexpr (TR) {
-            mma32(dvt[d], lds_tr_chunk(do_l, d, qa, ks, lane), pb);
-            mma32(dkt[d], lds_tr_chunk(q_l, d, qa, ks, lane), dsb);
+            mma32(dvt[d], lds_tr_chunk<T>(do_l, d, qa, ks, lane), pb);
+            mma32(dkt[d], lds_tr_chunk<T>(q_l, d, qa, ks, lane), dsb);
           } else {
             mma32(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
             mma32(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);

@@ -11,6 +11,10 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16_t;  // third activation dtype: IEEE half (11 significant bits: 8x less operand round-off than bf16 at the
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;  // same MFMA rate; the dgrad chain runs on a power-of-two
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;  // scaled gradient, seggpt_api.hip)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -22,6 +26,11 @@ template <> struct Traits<bf16_t> {
   typedef bf16x8 Chunk;
   typedef bf16x4 Vec4;
   static constexpr int EPC = 8;  // elements per 16-byte chunk
+};
+template <> struct Traits<f16_t> {
+  typedef f16x8 Chunk;
+  typedef f16x4 Vec4;
+  static constexpr int EPC = 8;
 };
 template <> struct Traits<float> {
   typedef f32x4 Chunk;
@@ -36,12 +45,18 @@ template <> struct Traits<float> {
 DEVI void mma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
+DEVI void mma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
 DEVI void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
 }
 DEVI void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+DEVI void mma32(f32x16& acc, const f16x8& a, const f16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
 }
 DEVI void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
 #pragma unroll
@@ -54,14 +69,19 @@ DEVI int acc32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; 
 // ---- conversions
 DEVI float to_f32(float x) { return x; }
 DEVI float to_f32(bf16_t x) { return (float)x; }
+DEVI float to_f32(f16_t x) { return (float)x; }
 template <typename T> DEVI T from_f32(float x);
 template <> DEVI float from_f32<float>(float x) { return x; }
 template <> DEVI bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+template <> DEVI f16_t from_f32<f16_t>(float x) { return (f16_t)x; }     // v_cvt_pk_f16_f32 (gfx950): RNE
 
 template <typename T> DEVI typename Traits<T>::Vec4 pack4(float a, float b, float c, float d);
 template <> DEVI f32x4 pack4<float>(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
 template <> DEVI bf16x4 pack4<bf16_t>(float a, float b, float c, float d) {
   return bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}
+template <> DEVI f16x4 pack4<f16_t>(float a, float b, float c, float d) {
+  return f16x4{(f16_t)a, (f16_t)b, (f16_t)c, (f16_t)d};
 }
 
 // two floats -> one 32-bit word of two 16-bit values (16-bit dtypes only)
@@ -70,11 +90,19 @@ template <> DEVI unsigned pack2<bf16_t>(float a, float b) {
   const bf16x2 v = bf16x2{(bf16_t)a, (bf16_t)b};
   return __builtin_bit_cast(unsigned, v);
 }
+template <> DEVI unsigned pack2<f16_t>(float a, float b) {
+  const f16x2 v = f16x2{(f16_t)a, (f16_t)b};
+  return __builtin_bit_cast(unsigned, v);
+}
 
 // chunk from 8 (bf16) or 4 (f32) floats held in two f32x4 (second ignored for f32)
 DEVI void chunk_from_f32(bf16x8& c, const float* v) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) c[j] = (bf16_t)v[j];
+}
+DEVI void chunk_from_f32(f16x8& c, const float* v) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = (f16_t)v[j];
 }
 
 // ---- async global -> LDS copy of one 16-byte chunk per lane (LDS-DMA).  `lds_wave_base` must be

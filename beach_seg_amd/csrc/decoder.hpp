@@ -362,7 +362,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ conv_out,
                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                         const float* __restrict__ head_w, T* __restrict__ dconv, int B,
-                                                        int H, int W, float eps, int row0) {
+                                                        int H, int W, float eps, int row0, const float* gscale) {
   const long hw = (long)H * W, win = (long)(H - row0) * W, total = (long)B * win;  // rows [row0, H) of every image
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const long pl = gid >> 2;
@@ -371,8 +371,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const int b = pl / win;
   const long yx = (long)row0 * W + pl % win;
   const long p = (long)b * hw + yx;
-  const float d0 = dpred[(long)b * 3 * hw + yx], d1 = dpred[(long)b * 3 * hw + hw + yx],
-              d2 = dpred[(long)b * 3 * hw + 2 * hw + yx];
+  const float gs = gscale ? gscale[0] : 1.0f;  // f16 mode: the dgrad chain runs on a power-of-two multiple of the gradient
+  const float d0 = dpred[(long)b * 3 * hw + yx] * gs, d1 = dpred[(long)b * 3 * hw + hw + yx] * gs,
+              d2 = dpred[(long)b * 3 * hw + 2 * hw + yx] * gs;
   typedef typename Traits<T>::Vec4 V4;
   V4* dst = (V4*)(dconv + p * 64 + c0);
   float v[16], g[16];

@@ -49,21 +49,17 @@ struct GemmArgs {
   int t_off;
   int o_rpg;
   long o_gstride, o_off;
+  const float* out_scale;  // EPI_UNPATCH: device scalar multiplied into the output (un-scaling of the fp16 gradient), or nullptr
   int group_m;  // v3: row tiles per L2 group (0 = 4)
   int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
 
 // ---- shared epilogue: acc[ni][mi][r] = C[mw + mi*16 + (lane&15)][nw + ni*16 + 4*(lane>>4) + r]
-DEVI unsigned pack_bf16x2(float a, float b) {
-  const bf16x2 v = bf16x2{(bf16_t)a, (bf16_t)b};
-  return __builtin_bit_cast(unsigned, v);
-}
-
-// bf16 outputs, N % 16 == 0: exchange register pairs between the four 16-lane rows (v_permlane16_swap) so every
+// 16-bit outputs, N % 16 == 0: exchange register pairs between the four 16-lane rows (v_permlane16_swap) so every
 // lane owns 8 consecutive columns -> 16-byte stores, 64 contiguous bytes per output row per instruction (the
 // narrow path writes 32-byte segments and doubles the number of memory requests of the tile's store burst).
-template <int EPI>
-DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
+template <typename T, int EPI>
+DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -80,15 +76,15 @@ DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw,
         f32x4 y, dy;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { float yy, dd; gelu_both_f(v[r], yy, dd); y[r] = yy; dy[r] = dd; }
-        lo2[ni] = pack_bf16x2(dy[0], dy[1]);
-        hi2[ni] = pack_bf16x2(dy[2], dy[3]);
+        lo2[ni] = pack2<T>(dy[0], dy[1]);
+        hi2[ni] = pack2<T>(dy[2], dy[3]);
         v = y;
       } else if (EPI == EPI_GELU_BWD) {
-        const bf16x4 hp = *(const bf16x4*)((const bf16_t*)g.aux + (long)mc * g.ldaux + n);
+        const typename Traits<T>::Vec4 hp = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)mc * g.ldaux + n);
         v = f32x4{v[0] * (float)hp[0], v[1] * (float)hp[1], v[2] * (float)hp[2], v[3] * (float)hp[3]};
       }
-      lo[ni] = pack_bf16x2(v[0], v[1]);
-      hi[ni] = pack_bf16x2(v[2], v[3]);
+      lo[ni] = pack2<T>(v[0], v[1]);
+      hi[ni] = pack2<T>(v[2], v[3]);
     }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -108,11 +104,11 @@ DEVI void gemm_epilogue_wide_bf16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw,
         const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
         off = orow * g.ldo + col;
       }
-      if (ok) *(u32x4*)((bf16_t*)g.out + off) = out;
+      if (ok) *(u32x4*)((T*)g.out + off) = out;
       if (EPI == EPI_BIAS_GELU) {
         auto q0 = __builtin_amdgcn_permlane16_swap(lo2[ia], lo2[ib], false, false);
         auto q1 = __builtin_amdgcn_permlane16_swap(hi2[ia], hi2[ib], false, false);
-        if (ok && g.out2) *(u32x4*)((bf16_t*)g.out2 + off) = u32x4{q0[0], q1[0], q0[1], q1[1]};
+        if (ok && g.out2) *(u32x4*)((T*)g.out2 + off) = u32x4{q0[0], q1[0], q0[1], q1[1]};
       }
     }
   }
@@ -123,7 +119,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
   if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
-      gemm_epilogue_wide_bf16<EPI>(g, acc, mw, nw, frow, fchunk);
+      gemm_epilogue_wide16<T, EPI>(g, acc, mw, nw, frow, fchunk);
       return;
     }
   }
@@ -177,7 +173,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         const int ph = t / g.wp, pw = t % g.wp;
         const int c = n >> 8, i = (n >> 4) & 15, j = n & 15;
         const long o = (((long)b * 3 + c) * (g.himg >> 1) + ph * 16 + i) * g.wimg + pw * 16 + j;
-        *(f32x4*)((float*)g.out + o) = v;
+        *(f32x4*)((float*)g.out + o) = g.out_scale ? v * g.out_scale[0] : v;
       }
     }
   }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/beach_seg_amd.h"
@@ -124,6 +125,7 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
     p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
     if (m->c.embed_split) p.add("dx_split", -1, (size_t)B * (N / 2) * 3 * D * es);
+    p.add("gscale", -1, 256);  // f16: [S, 1/S] of the dgrad chain + the |grad_pred| max behind it
   }
   return p;
 }
@@ -284,11 +286,9 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       CHECK_LAUNCH();
     }
     {
-      // bf16: the PV operand comes straight from the row-major V tile through transposing LDS reads; f32 (no
+      // 16-bit dtypes: the PV operand comes straight from the row-major V tile through transposing LDS reads; f32 (no
       // 32-bit transposing read on gfx950) keeps the row-padded V^T copy.
-      static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
-      constexpr bool can_tr = sizeof(T) == 2;
-      const bool tr = can_tr && tr_env;
+      constexpr bool tr = sizeof(T) == 2;
       if (!tr) {
         const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
         hipLaunchKernelGGL((head_transpose_kernel<T>), dim3(hp, nh / hb, S), dim3(256), 0, st, qkv + 2 * D, (long)3 * D, vt, N,
@@ -298,15 +298,13 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       AttnArgs a{};
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.vt = vt; a.rel_cat = m->lw(l, 18); a.relhT = relh_s; a.out = attn_o;
       a.ldo = D; a.lse2 = lse2; a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static const int ldspad = getenv("BSG_ATTN_LDS_PAD") ? atoi(getenv("BSG_ATTN_LDS_PAD")) : 0;  // occupancy experiments
-      static bool once2 = (allow_lds(attn_fwd_kernel<T, false>, 160 * 1024), allow_lds(attn_fwd_kernel<T, can_tr>, 160 * 1024), true);
+      static bool once2 = (allow_lds(attn_fwd_kernel<T, tr>, 160 * 1024), true);
       (void)once2;
       ProfScope ps(m, st, PC_ATTN_FWD, 4.0 * S * nh * (double)N * N * 64);
       const dim3 agrid(((N + 127) / 128) * nh * S);
       const int relh_lds = 4 * 32 * (hp | 1) * 4;  // prologue scratch (32 x HS relh table per wave) aliases the tiles
-      const int lds = std::max(4 * AttnK<T>::TILE, relh_lds) + ldspad;
-      if (tr) hipLaunchKernelGGL((attn_fwd_kernel<T, can_tr>), agrid, dim3(256), lds, st, a);
-      else hipLaunchKernelGGL((attn_fwd_kernel<T, false>), agrid, dim3(256), lds, st, a);
+      const int lds = std::max(4 * AttnK<T>::TILE, relh_lds);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, tr>), agrid, dim3(256), lds, st, a);
       CHECK_LAUNCH();
     }
     {
@@ -407,6 +405,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   float* delta = c.template at<float>("delta");
   float* relhT = c.template at<float>("relhT");
   float* relwT = c.template at<float>("relwT");
+  float* gscale = std::is_same<T, f16_t>::value ? c.template at<float>("gscale") : nullptr;
 
   {
     // grad_pred is zero on canvas rows < first_row (the reference loss only covers the bottom half, src/model.py:53-57):
@@ -414,9 +413,17 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     const int ph0 = first_row > 0 ? (first_row - 1) / 16 : 0;
     const int hb0 = std::max(0, 16 * ph0 - 8), ty0 = ph0, ntok = (hp - ph0) * wp;  // ty0: first 16-row conv tile = first token row
     const long total = (long)B * (H - hb0) * W;
+    if (gscale) {  // f16: S = 2^k from max |grad_pred| (device side), so that the half-precision dgrad chain stays in range
+      unsigned* amax = (unsigned*)(gscale + 8);
+      if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return fail("memset failed");
+      const long n4 = (long)B * 3 * H * W / 4;
+      hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, dpred, n4, amax);
+      hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)amax, gscale, 8);
+      CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
                        c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
-                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0);
+                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0, (const float*)gscale);
     CHECK_LAUNCH();
     ConvArgs a{};
     a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
@@ -475,9 +482,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       CHECK_LAUNCH();
     }
     {  // attention backward on the B image streams
-      static const bool tr_env = !getenv("BSG_ATTN_NO_TR");
-      constexpr bool can_tr = sizeof(T) == 2;  // bf16: K^T / Q^T / dO^T operands via transposing LDS reads of the row-major tiles
-      const bool tr = can_tr && tr_env;
+      constexpr bool tr = sizeof(T) == 2;  // 16-bit: K^T / Q^T / dO^T operands via transposing LDS reads of the row-major tiles
       if (!tr) {
         const int hb = nh % 4 == 0 ? 4 : (nh % 2 == 0 ? 2 : 1);
         const int npad = hp * 32, dg = 2 * ((N + 63) / 64);  // key side: one group per grid row; query side: dense tokens
@@ -491,29 +496,26 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.rel_cat = m->lw(l, 18);
       a.rel_catT = m->lw(l, 19); a.relhT = relhT; a.relwT = relwT; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
-      static bool once = (allow_lds(attn_bwd_dq_kernel<T, false>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, can_tr>, 160 * 1024), true);
+      static bool once = (allow_lds(attn_bwd_dq_kernel<T, tr>, 160 * 1024), true);
       (void)once;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
         const dim3 qgrid(((N + 127) / 128) * nh * B);
         const int relh_lds = 4 * 32 * (hp | 1) * 4;
-        if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, can_tr>), qgrid, dim3(256), 4 * AttnK<T>::TILE + relh_lds, st, a);
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false>), qgrid, dim3(256), 6 * AttnK<T>::TILE + relh_lds, st, a);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, tr>), qgrid, dim3(256), (tr ? 4 : 6) * AttnK<T>::TILE + relh_lds, st, a);
       }
       CHECK_LAUNCH();
       AttnBwdKvArgs k{};
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
-      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, false>, 2 * DkvK<T, false>::STAGE),
-                           allow_lds(attn_bwd_dkv_kernel<T, can_tr>, 2 * DkvK<T, can_tr>::STAGE), true);
+      constexpr int lds_kv = 2 * DkvK<T, tr>::STAGE;
+      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, tr>, lds_kv), true);
       (void)once2;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
         const dim3 kgrid(((hp + 7) / 8) * nh * B);
-        constexpr int lds_tr = 2 * DkvK<T, can_tr>::STAGE, lds_t = 2 * DkvK<T, false>::STAGE;
-        if (tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, can_tr>), kgrid, dim3(512), lds_tr, st, k);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false>), kgrid, dim3(512), lds_t, st, k);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, tr>), kgrid, dim3(512), lds_kv, st, k);
       }
       CHECK_LAUNCH();
     }
@@ -539,6 +541,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       g.A = dxs; g.K = 3 * D; g.lda = 3 * D; g.a_rpg = 0; g.a_gstride = 0;
     }
     g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W; g.out = gprompt;
+    g.out_scale = gscale ? gscale + 1 : nullptr;  // f16: 1 / S
     gemm<T, A_PLAIN, EPI_UNPATCH>(m, g, st);
     CHECK_LAUNCH();
   }
@@ -554,7 +557,7 @@ const char* bsg_build_info(void) { return "beach_seg_amd hip kernels, gfx950, bu
 int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights, bsg_model** out) {
   if (!cfg || !weights || !out) return fail("bsg_create: null argument");
   const bsg_config& c = *cfg;
-  if (c.dtype != BSG_DTYPE_F32 && c.dtype != BSG_DTYPE_BF16) return fail("dtype must be 0 (f32) or 1 (bf16)");
+  if (c.dtype != BSG_DTYPE_F32 && c.dtype != BSG_DTYPE_BF16 && c.dtype != BSG_DTYPE_F16) return fail("dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   if (c.patch_size != 16) return fail("patch_size must be 16");
   if (c.decoder_hidden != 64) return fail("decoder_hidden must be 64");
   if (c.num_heads <= 0 || c.hidden_size != c.num_heads * 64) return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
@@ -567,7 +570,7 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
     if (c.taps[i] < c.merge_index || c.taps[i] >= c.num_layers) return fail("tap index %d out of range", c.taps[i]);
   if (c.merge_index < 0 || c.merge_index >= c.num_layers) return fail("merge_index out of range");
   if (c.embed_split != 0 && c.embed_split != 1) return fail("embed_split must be 0 or 1");
-  if (c.embed_split && c.dtype == BSG_DTYPE_F32) return fail("embed_split applies to the bf16 dtype only");
+  if (c.embed_split && c.dtype == BSG_DTYPE_F32) return fail("embed_split applies to the 16-bit dtypes only");
   const int need = BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * c.num_layers;
   if (n_weights != need) return fail("weight table has %d entries, expected %d", n_weights, need);
   for (int i = 0; i < need; ++i) if (!weights[i]) return fail("weight table entry %d is null", i);
@@ -642,9 +645,9 @@ int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values
   if (workspace_bytes < bsg_workspace_bytes(m, batch, save_for_backward))
     return fail("workspace too small: %zu < %zu", workspace_bytes, bsg_workspace_bytes(m, batch, save_for_backward));
   hipStream_t st = (hipStream_t)stream;
-  return m->c.dtype == BSG_DTYPE_F32
-             ? forward_impl<float>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward)
-             : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward);
+#define BSG_FWD(TT) forward_impl<TT>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward)
+  return m->c.dtype == BSG_DTYPE_F32 ? BSG_FWD(float) : m->c.dtype == BSG_DTYPE_BF16 ? BSG_FWD(bf16_t) : BSG_FWD(f16_t);
+#undef BSG_FWD
 }
 
 int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
@@ -656,9 +659,9 @@ int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pix
     return fail("Embedding type should be either 'semantic' or 'instance', but got %d", embedding_type);
   if (workspace_bytes < bsg_workspace_bytes(m, batch, 0)) return fail("workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  return m->c.dtype == BSG_DTYPE_F32
-             ? forward_impl<float>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1)
-             : forward_impl<bf16_t>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1);
+#define BSG_FWD(TT) forward_impl<TT>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, 0, 1)
+  return m->c.dtype == BSG_DTYPE_F32 ? BSG_FWD(float) : m->c.dtype == BSG_DTYPE_BF16 ? BSG_FWD(bf16_t) : BSG_FWD(f16_t);
+#undef BSG_FWD
 }
 
 int bsg_backward_rows(bsg_model* m, void* stream, int batch, const float* grad_pred, int first_row,
@@ -667,9 +670,9 @@ int bsg_backward_rows(bsg_model* m, void* stream, int batch, const float* grad_p
   if (workspace_bytes < bsg_workspace_bytes(m, batch, 1)) return fail("workspace too small for backward");
   if (first_row < 0 || first_row >= m->c.canvas_h) return fail("first_row %d outside the canvas", first_row);
   hipStream_t st = (hipStream_t)stream;
-  return m->c.dtype == BSG_DTYPE_F32
-             ? backward_impl<float>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace, first_row)
-             : backward_impl<bf16_t>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace, first_row);
+#define BSG_BWD(TT) backward_impl<TT>(m, st, batch, grad_pred, grad_prompt_pixel_values, workspace, first_row)
+  return m->c.dtype == BSG_DTYPE_F32 ? BSG_BWD(float) : m->c.dtype == BSG_DTYPE_BF16 ? BSG_BWD(bf16_t) : BSG_BWD(f16_t);
+#undef BSG_BWD
 }
 
 int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values, void* workspace,

@@ -99,7 +99,9 @@ class PromptModel(torch.nn.Module):
         self.conf = conf
         self.num_classes = len(conf.classes)
         self.nodata_idx = 0
-        dtype = torch.float32 if conf.precision.startswith("32") else torch.bfloat16
+        # Lightning precision strings (src/config.py:35): "32-true" -> exact-f32 kernels, "bf16-*" -> bf16, "16-*" -> IEEE half
+        dtype = (torch.float32 if conf.precision.startswith("32") else
+                 torch.float16 if conf.precision.startswith("16") else torch.bfloat16)
         self.model = model if model is not None else ml_util.load_model(conf.checkpoint, device=device, dtype=dtype)
         self.train_metrics = MulticlassF1(self.num_classes, self.nodata_idx, self.model.device)
         self.val_metrics = MulticlassF1(self.num_classes, self.nodata_idx, self.model.device)

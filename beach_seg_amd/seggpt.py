@@ -176,7 +176,9 @@ class _SegGptFn(torch.autograd.Function):
 
 
 class SegGptNative(torch.nn.Module):
-    """Frozen SegGPT on the HIP kernels.  `dtype`: torch.float32 (parity mode) or torch.bfloat16."""
+    """Frozen SegGPT on the HIP kernels.  `dtype`: torch.float32 (parity mode, exact-f32 MFMA), torch.bfloat16 (the
+    dtype BASELINE config 1 names) or torch.float16 (same MFMA rate as bf16 with 8x less operand round-off; the backward
+    runs on a device-chosen power-of-two multiple of the gradient)."""
 
     def __init__(self, state_dict: dict, geometry: SegGptGeometry, device="cuda:0", dtype=torch.bfloat16,
                  embed_split: Optional[bool] = None):
@@ -184,8 +186,8 @@ class SegGptNative(torch.nn.Module):
         the prompt-pixel gradient are not quantised to the MFMA operand type (`bsg_config.embed_split`)."""
         super().__init__()
         geometry.validate()
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("dtype must be torch.float32 or torch.bfloat16")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("dtype must be torch.float32, torch.bfloat16 or torch.float16")
         self.geometry, self.dtype = geometry, dtype
         self._device = torch.device(device)
         self._lib = N.load()
@@ -202,7 +204,7 @@ class SegGptNative(torch.nn.Module):
         for i, t in enumerate(g.intermediate_hidden_state_indices):
             cfg.taps[i] = t
         cfg.layer_norm_eps = g.layer_norm_eps
-        cfg.dtype = N.BSG_DTYPE_F32 if dtype == torch.float32 else N.BSG_DTYPE_BF16
+        cfg.dtype = {torch.float32: N.BSG_DTYPE_F32, torch.bfloat16: N.BSG_DTYPE_BF16, torch.float16: N.BSG_DTYPE_F16}[dtype]
         cfg.embed_split = int(self.embed_split)
         ptrs = (C.c_void_p * len(self._table))(*[t.data_ptr() for t in self._table])
         h = C.c_void_p()

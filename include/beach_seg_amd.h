@@ -25,6 +25,9 @@ extern "C" {
 
 #define BSG_DTYPE_F32 0  /* parity mode: fp32 storage, exact-f32 MFMA */
 #define BSG_DTYPE_BF16 1 /* throughput mode: bf16 storage / bf16 MFMA, fp32 accumulate + fp32 residual stream */
+#define BSG_DTYPE_F16 2  /* IEEE-half storage / f16 MFMA (same rate as bf16, 8x less operand round-off), fp32 accumulate +
+                            fp32 residual stream; the dgrad chain runs on a power-of-two multiple of the gradient chosen on
+                            device from max |grad_pred| (halves hold 6e-5 .. 65504) and is un-scaled in the last GEMM */
 #define BSG_MAX_TAPS 8
 #define BSG_GLOBAL_WEIGHTS 16 /* weight-table slots before the per-layer blocks */
 #define BSG_LAYER_WEIGHTS 20  /* slots per encoder layer */

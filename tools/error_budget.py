@@ -78,7 +78,7 @@ def main():
     d = ((x[:, :, :, None, :] - inputs[5][:, None, None, :, :]) ** 2).sum(-1)
     top2 = d.topk(2, dim=-1, largest=False).values
     margin = (top2[..., 1] - top2[..., 0])
-    variants = [("bf16_split", torch.bfloat16, True), ("bf16_nosplit", torch.bfloat16, False)]
+    variants = [("f16_split", torch.float16, True), ("bf16_split", torch.bfloat16, True), ("bf16_nosplit", torch.bfloat16, False)]
     for name, dt, split in variants:
         model = SegGptNative(sd, g, device=DEV, dtype=dt, embed_split=split)
         got = run(model, g, B, inputs, dt)
