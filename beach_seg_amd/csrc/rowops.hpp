@@ -151,30 +151,32 @@ __global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __
 template <typename T>
 __global__ void patchify_kernel(const float* __restrict__ prompt_img, const float* __restrict__ query_img,
                                 const float* __restrict__ prompt_mask, T* __restrict__ A, int B, int hp, int wp, int split) {
+  // one thread per (row m, channel c, patch row i, half j8): 8 pixels in (32 B), 8 elements out per copy (16 B when T is
+  // 16-bit): consecutive threads write consecutive 16-byte chunks of the A row, so every store instruction is one
+  // contiguous run (an earlier 4 x 8-byte-per-lane form wrote partial lines: 3.6x write amplification in WRITE_SIZE)
   const int N = hp * wp, hh = hp / 2;
-  const long total = (long)2 * B * N * 48;
+  const long total = (long)2 * B * N * 96;
   const int Hh = hh * 16, W = wp * 16;
   const long lda = split ? 3 * 768 : 768;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int ci = idx % 48;
-    const long m = idx / 48;
-    const int c = ci / 16, i = ci % 16;
+    const int cj = idx % 96;
+    const long m = idx / 96;
+    const int c = cj / 32, i = (cj % 32) >> 1, j8 = cj & 1;
     const int s = m / N, t = m % N, ph = t / wp, pw = t % wp;
     const float* src = nullptr;
-    if (s < B) src = (ph < hh ? prompt_img : query_img) + (((long)s * 3 + c) * Hh + (ph % hh) * 16 + i) * W + pw * 16;
-    else if (ph < hh) src = prompt_mask + (((long)(s - B) * 3 + c) * Hh + ph * 16 + i) * W + pw * 16;
-    T* dst = A + m * lda + c * 256 + i * 16;
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (src) v = *(const f32x4*)(src + 4 * j4);
-      const typename Traits<T>::Vec4 hi = pack4<T>(v[0], v[1], v[2], v[3]);
-      *(typename Traits<T>::Vec4*)(dst + 4 * j4) = hi;
-      if (split) {  // [hi | hi | lo]: with the weight laid out [W_hi | W_lo | W_hi] one K = 3*768 GEMM sums hi*W_hi + hi*W_lo + lo*W_hi
-        *(typename Traits<T>::Vec4*)(dst + 768 + 4 * j4) = hi;
-        *(typename Traits<T>::Vec4*)(dst + 1536 + 4 * j4) =
-            pack4<T>(v[0] - to_f32(hi[0]), v[1] - to_f32(hi[1]), v[2] - to_f32(hi[2]), v[3] - to_f32(hi[3]));
-      }
+    if (s < B) src = (ph < hh ? prompt_img : query_img) + (((long)s * 3 + c) * Hh + (ph % hh) * 16 + i) * W + pw * 16 + j8 * 8;
+    else if (ph < hh) src = prompt_mask + (((long)(s - B) * 3 + c) * Hh + ph * 16 + i) * W + pw * 16 + j8 * 8;
+    T* dst = A + m * lda + c * 256 + i * 16 + j8 * 8;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (src) { v0 = *(const f32x4*)src; v1 = *(const f32x4*)(src + 4); }
+    typedef typename Traits<T>::Vec4 V4;
+    const V4 h0 = pack4<T>(v0[0], v0[1], v0[2], v0[3]), h1 = pack4<T>(v1[0], v1[1], v1[2], v1[3]);
+    struct alignas(2 * sizeof(V4)) Pair { V4 a, b; };
+    *(Pair*)dst = Pair{h0, h1};
+    if (split) {  // [hi | hi | lo]: with the weight laid out [W_hi | W_lo | W_hi] one K = 3*768 GEMM sums hi*W_hi + hi*W_lo + lo*W_hi
+      *(Pair*)(dst + 768) = Pair{h0, h1};
+      *(Pair*)(dst + 1536) = Pair{pack4<T>(v0[0] - to_f32(h0[0]), v0[1] - to_f32(h0[1]), v0[2] - to_f32(h0[2]), v0[3] - to_f32(h0[3])),
+                                  pack4<T>(v1[0] - to_f32(h1[0]), v1[1] - to_f32(h1[1]), v1[2] - to_f32(h1[2]), v1[3] - to_f32(h1[3]))};
     }
   }
 }

@@ -254,7 +254,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   T* feat = c.template at<T>("feat");
 
   {
-    const long total = (long)2 * B * N * 48;
+    const long total = (long)2 * B * N * 96;
     hipLaunchKernelGGL((patchify_kernel<T>), dim3((unsigned)std::min<long>((total + 255) / 256, 65535 * 16)), dim3(256), 0, st,
                        prm, pix, pmask, patch_a, B, hp, wp, m->c.embed_split);
     CHECK_LAUNCH();
