@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                           (float*)(smem + wave * 8192), relh_q - col * relh_stride(a.hp), rwv, lane);
   ATTN_STAMP(0);  // loads of q / dO + rel-pos tables
   // publish the key-major copies the dK/dV kernel streams (lane = key there): 128-byte row segments per half-wave
-  if (q0 + col < ((a.N + 63) & ~63)) {
-    const bool real = q0 + col < a.N;  // tail columns up to the dK/dV tile boundary: -inf bias, i.e. P = 0
+  if (q0 + col < min((a.N + 127) & ~127, npad)) {
+    const bool real = q0 + col < a.N;  // tail columns up to the dK/dV tile boundary (64 or 128 queries): -inf bias, i.e. P = 0
     float* wT = a.relwT + sh * 32 * npad + q0 + col;
 #pragma unroll
     for (int r = 0; r < 16; ++r) wT[(long)acc32_row(r, h) * npad] = real ? rwv[r] : -INFINITY;
@@ -685,27 +685,32 @@ DEVI void dma_rows(char* lds_tile, int wave, int lane, RowSrc row_src) {
   }
 }
 
-template <typename T, bool TR> struct DkvK {
-  static constexpr int TILE = AttnK<T>::TILE;
+template <typename T, bool TR, int QT = 64> struct DkvK {
+  static constexpr int TILE = QT * AttnK<T>::RB;  // QT query rows
   static constexpr int NTILE = TR ? 2 : 4;
-  static constexpr int STAGE = NTILE * TILE + 8192 + 4096;  // Q | dO | (QT | dOT) | relwT [32][64 f32] | stats [16][64 f32]
+  static constexpr int RW = 32 * QT * 4, STATS = 16 * QT * 4;
+  static constexpr int STAGE = NTILE * TILE + RW + STATS;  // Q | dO | (QT | dOT) | relwT [32][QT f32] | stats [16][QT f32]
 };
 
 // Eight waves per workgroup, each owning ONE grid row of keys (32 slots): dK^T, dV^T of that row stay in 64
 // accumulator registers, so two waves fit per SIMD.  The per-query statistics (lse2, delta, rel-pos rows) ride the
 // same LDS-DMA stream as the Q / dO tiles instead of occupying 128 registers.
-template <typename T, bool TR>
+// QT = queries per streamed tile (64 or 128): a tile costs one workgroup barrier + one DMA wait for all 8 waves, so the
+// 128-query form halves the synchronisations (112 KB of LDS for the two stages; 16-bit dtypes only).
+template <typename T, bool TR, int QT = 64>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
+  typedef DkvK<T, TR, QT> K_;
   static_assert(TR == (sizeof(T) == 2), "16-bit dtypes take the transposing-read path, f32 the transposed copies");
-  constexpr int RB = C::RB, STAGE = DkvK<T, TR>::STAGE, NTILE = DkvK<T, TR>::NTILE;
+  static_assert(QT == 64 || (QT == 128 && TR), "128-query tiles: transposing-read path only");
+  constexpr int RB = C::RB, STAGE = K_::STAGE, NTILE = K_::NTILE, QB = QT * 4;  // QB: bytes of one f32 table row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
   attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
-  const int nt = (a.N + 63) >> 6;
+  const int nt = (a.N + QT - 1) / QT;
   const int kr0 = bx * 8;
   const bool wave_valid = kr0 + wave < a.hp;
   const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
@@ -735,26 +740,26 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 
   auto issue = [&](int t, int buf) {
     char* base = smem + buf * STAGE;
-    dma_rows<RB, 64, 8, true>(base, wave, lane, [&](int r) {
-      return qbase + (long)min(t * 64 + r, a.N - 1) * a.ld * sizeof(T);
+    dma_rows<RB, QT, 8, true>(base, wave, lane, [&](int r) {
+      return qbase + (long)min(t * QT + r, a.N - 1) * a.ld * sizeof(T);
     });
-    dma_rows<RB, 64, 8, true>(base + C::TILE, wave, lane, [&](int r) {
-      return dobase + (long)min(t * 64 + r, a.N - 1) * a.ldo * sizeof(T);
+    dma_rows<RB, QT, 8, true>(base + K_::TILE, wave, lane, [&](int r) {
+      return dobase + (long)min(t * QT + r, a.N - 1) * a.ldo * sizeof(T);
     });
     if constexpr (!TR) {
-      dma_rows<RB, 64, 8, true>(base + 2 * C::TILE, wave, lane,
+      dma_rows<RB, 64, 8, true>(base + 2 * K_::TILE, wave, lane,
                                 [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
-      dma_rows<RB, 64, 8, true>(base + 3 * C::TILE, wave, lane,
+      dma_rows<RB, 64, 8, true>(base + 3 * K_::TILE, wave, lane,
                                 [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
     }
-    dma_rows<256, 32, 8, true>(base + NTILE * C::TILE, wave, lane, [&](int r) {
-      return (const char*)(a.relwT + (sh * 32 + r) * npad + t * 64);
+    dma_rows<QB, 32, 8, true>(base + NTILE * K_::TILE, wave, lane, [&](int r) {
+      return (const char*)(a.relwT + (sh * 32 + r) * npad + t * QT);
     });
-    dma_rows<256, 16, 8, false>(base + NTILE * C::TILE + 8192, wave, lane, [&](int r) {
+    dma_rows<QB, 16, 8, false>(base + NTILE * K_::TILE + K_::RW, wave, lane, [&](int r) {
       const float* p = r == 0 ? a.lse2 + sh * npad
                      : r == 1 ? a.delta + sh * npad
                               : a.relhT + (sh * a.hp + min(kr0 + max(r - 2, 0), a.hp - 1)) * npad;
-      return (const char*)(p + t * 64);
+      return (const char*)(p + t * QT);
     });
   };
 
@@ -765,20 +770,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
     __syncthreads();
     if (t + 1 < nt) issue(t + 1, buf ^ 1);
     const char* q_l = smem + buf * STAGE;
-    const char* do_l = q_l + C::TILE;
-    const char* qt_l = q_l + 2 * C::TILE;   // !TR only
-    const char* dot_l = q_l + 3 * C::TILE;  // !TR only
-    const char* rw_l = q_l + NTILE * C::TILE + col * 256;
-    const char* st_l = q_l + NTILE * C::TILE + 8192;
+    const char* do_l = q_l + K_::TILE;
+    const char* qt_l = q_l + 2 * K_::TILE;   // !TR only
+    const char* dot_l = q_l + 3 * K_::TILE;  // !TR only
+    const char* rw_l = q_l + NTILE * K_::TILE + col * QB;
+    const char* st_l = q_l + NTILE * K_::TILE + K_::RW;
 #pragma unroll
-    for (int qa = 0; qa < 2; ++qa) {
+    for (int qa = 0; qa < QT / 32; ++qa) {
       f32x16 st, dp;
       f32x4 rhl4[4];  // relh * c2 - lse2 of this wave's key row, per query slot (pre-folded by the dQ kernel)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = qa * 8 + 2 * i + h;  // 16-byte chunk holding query slots qa*32 + 8i + 4h .. +3
-        const f32x4 dl4 = *(const f32x4*)(st_l + 256 + c * 16);
-        rhl4[i] = *(const f32x4*)(st_l + (2 + wave) * 256 + c * 16);
+        const f32x4 dl4 = *(const f32x4*)(st_l + QB + c * 16);
+        rhl4[i] = *(const f32x4*)(st_l + (2 + wave) * QB + c * 16);
         const f32x4 rw = *(const f32x4*)(rw_l + ((c ^ (col & 15)) << 4));
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j]; dp[4 * i + j] = dl4[j]; }  // S starts from relwT, dP from -delta

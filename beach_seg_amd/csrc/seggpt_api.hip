@@ -216,6 +216,27 @@ template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int B
   hipLaunchKernelGGL((conv3x3_kernel<T, MODE>), dim3(a.W / 32, a.H / CONV_TR - ty0, B), dim3(256), CONV_HALO * 64 * sizeof(T), st, b);
 }
 
+// dK/dV launch: 16-bit dtypes stream 128-query tiles when the padded statistics rows hold the rounded-up length
+// (BSG_DKV_QT=64 forces the 64-query form: A/B runs)
+template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t st) {
+  constexpr bool tr = sizeof(T) == 2;
+  const dim3 kgrid(((k.hp + 7) / 8) * k.nh * k.S);
+  if constexpr (tr) {
+    static const int qt_env = getenv("BSG_DKV_QT") ? atoi(getenv("BSG_DKV_QT")) : 128;
+    if (qt_env == 128 && ((k.N + 127) & ~127) <= k.hp * 32) {
+      constexpr int lds = 2 * DkvK<T, true, 128>::STAGE;
+      static bool once = (allow_lds(attn_bwd_dkv_kernel<T, true, 128>, lds), true);
+      (void)once;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, 128>), kgrid, dim3(512), lds, st, k);
+      return;
+    }
+  }
+  constexpr int lds = 2 * DkvK<T, tr, 64>::STAGE;
+  static bool once = (allow_lds(attn_bwd_dkv_kernel<T, tr, 64>, lds), true);
+  (void)once;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, tr, 64>), kgrid, dim3(512), lds, st, k);
+}
+
 template <typename T> struct Ctx {
   const bsg_model* m;
   hipStream_t st;
@@ -509,13 +530,9 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
-      constexpr int lds_kv = 2 * DkvK<T, tr>::STAGE;
-      static bool once2 = (allow_lds(attn_bwd_dkv_kernel<T, tr>, lds_kv), true);
-      (void)once2;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
-        const dim3 kgrid(((hp + 7) / 8) * nh * B);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, tr>), kgrid, dim3(512), lds_kv, st, k);
+        launch_dkv<T>(k, st);
       }
       CHECK_LAUNCH();
     }
@@ -803,8 +820,7 @@ int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, con
   float* relwT = relhT + per * hp;
   float* delta = relwT + per * 32;
   const T* q = (const T*)qkv;
-  static bool once = (allow_lds(attn_fwd_kernel<T, true>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, true>, 160 * 1024),
-                      allow_lds(attn_bwd_dkv_kernel<T, true>, 2 * DkvK<T, true>::STAGE), true);
+  static bool once = (allow_lds(attn_fwd_kernel<T, true>, 160 * 1024), allow_lds(attn_bwd_dq_kernel<T, true>, 160 * 1024), true);
   (void)once;
   const int relh_lds = 4 * 32 * (hp | 1) * 4;
   if (which & 1) {
@@ -840,8 +856,7 @@ int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, con
     k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
     k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
     k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
-    constexpr int lds_kv = 2 * DkvK<T, true>::STAGE;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true>), dim3(((hp + 7) / 8) * nh * S), dim3(512), lds_kv, st, k);
+    launch_dkv<T>(k, st);
     CHECK_LAUNCH();
   }
   return 0;

@@ -119,6 +119,32 @@ def test_accumulator_finalises_the_previous_date():
         assert np.array_equal(got.cpu().numpy(), PO.vote_argmax(counter).astype(np.uint8))
 
 
+def test_load_model_from_checkpoint_files(tmp_path):
+    """`load_model(path)` (`src/util/ml_util.py:7-13` with a LOCAL checkpoint: the hub name needs network): a
+    `.safetensors` file and a `torch.save`d state dict (loaded with weights_only=True) give the same network as the
+    in-memory state dict, and a missing file raises."""
+    from safetensors.torch import save_file
+
+    geo = SegGptGeometry.tiny()
+    sd = synth_state_dict(geo, seed=4)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "ck.safetensors"))
+    torch.save(sd, tmp_path / "ck.pt")
+    g = torch.Generator().manual_seed(1)
+    x = [torch.randn(2, 3, 64, 64, generator=g).to(DEV) for _ in range(3)]
+    with torch.no_grad():
+        want = SegGptNative(sd, geo, device=DEV, dtype=torch.float32)(pixel_values=x[0], prompt_pixel_values=x[1], prompt_masks=x[2]).pred_masks
+        for name in ("ck.safetensors", "ck.pt"):
+            net = ml_util.load_model(str(tmp_path / name), device=DEV, dtype=torch.float32, geometry=geo)
+            got = net(pixel_values=x[0], prompt_pixel_values=x[1], prompt_masks=x[2]).pred_masks
+            assert torch.equal(got, want), name
+    with pytest.raises(FileNotFoundError):
+        ml_util.load_model("BAAI/seggpt-vit-large", device=DEV)
+    bad = dict(sd)
+    bad.pop("decoder.decoder_pred.head.bias")
+    with pytest.raises(KeyError):
+        SegGptNative(bad, geo, device=DEV)
+
+
 def test_hipgraph_replay_equals_eager_forward():
     """BASELINE config 4: the forward is capturable (no allocation / synchronisation inside the C ABI) and a graph
     replay reproduces the eager launch sequence bit for bit."""
