@@ -135,6 +135,21 @@ template <int OFF> DEVI f32x2 lds_read8tr_nw(unsigned addr) {  // transposing 4 
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
   return v;
 }
+// global -> register load / register -> LDS store that hipcc does not count (register-staged operand pipeline of
+// gemm_nt_kernel_v4): SGPR base + 32-bit per-lane offset; the caller waits with vmcnt / lgkmcnt before use.
+DEVI const char* uniform_ptr(const char* p) {  // makes wave-uniformity provable to hipcc (an "s" asm operand needs it)
+  const unsigned long v = (unsigned long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long)hi << 32) | lo);
+}
+DEVI f32x4 global_load16_nw(const void* sbase, unsigned voff) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+template <int OFF> DEVI void lds_write16_nw(unsigned addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" ::"v"(addr), "v"(v), "i"(OFF) : "memory");
+}
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- loop indices usable as asm immediates
 template <int I, int N, typename F> DEVI void static_for(F&& f) {
   if constexpr (I < N) {

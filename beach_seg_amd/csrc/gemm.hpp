@@ -617,6 +617,184 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 #endif
 }
 
+#ifdef BSG_GEMM_V4  // experiment build only (-DBSG_GEMM_V4, then BSG_GEMM=4): measured level with v3, see DESIGN.md section 8
+// ------------------------------------------------------------------------------------------------------------
+// v4 (16-bit dtypes, plain rows, M and N multiples of 256): 256 x 256 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 8 x 8
+// accumulator tiles = 256 registers kept in the accumulator half of the register file (MFMAs issued through asm with an
+// "a"-class accumulator: hipcc then leaves them in place; with the builtin it shuffles ~250 registers between the two
+// halves every K tile).  One wave per SIMD: 32 fragment reads per K tile feed 128 MFMAs (v3: 24 per 64).  There is no
+// partner wave to hide loads behind, and an LDS-DMA instruction holds the issue port ~60 cycles (measured: the same loop
+// with LDS-DMA operands 1.17 PFLOP/s, without the 16 DMA issues per K tile 1.76), so operands are REGISTER-STAGED:
+// global_load_dwordx4 (SGPR base + lane offset, one tile ahead in 64 registers) -> ds_write_b128 into the other LDS
+// buffer, all through uncounted asm slipped into the gaps of the wave's own MFMA stream; two barriers per K tile.
+// Measured (M 100,352, N 16,384, K 4,096, one box): v4 1.34 PFLOP/s, v3 1.36, hipBLASLt 1.58; v4 with every lane of the
+// staged loads reading ONE address (same instruction stream, no operand traffic) 1.70 -- the 64 KiB per K tile and CU
+// that a 256 x 256 tile pulls from L2 (10.6 TB/s chip-wide at 1.36 PFLOP/s), not instruction issue, is what both
+// kernels wait on.  Kept as an experiment; v3 stays the product kernel.
+DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, bf16_t) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v4(GemmArgs g) {
+  static_assert(sizeof(T) == 2, "v4: 16-bit operands");
+  constexpr int BK = 64, BUF = 65536;  // A 256 x 128 B, then W 256 x 128 B
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8;
+  const int nwg = tiles_m * tiles_n;
+  const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fchunk = lane >> 4;
+  const unsigned base = lds_addr(smem);
+  // fragment rows: wm*128 + i*16 + frow (i*16 rows = +2048 B immediates); chunk (fchunk + 4 ks) ^ (row & 7), row & 7 = frow & 7
+  const unsigned aA0 = base + (wm * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4), aA1 = aA0 ^ 64;
+  const unsigned aW0 = base + 32768 + (wn * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4), aW1 = aW0 ^ 64;
+  const int nk = g.K / BK;
+  // staging: instruction i of this wave covers rows wave*64 + i*8 + prow of the A tile (i < 8) / W tile (i >= 8); lane
+  // (prow, pchunk) loads source chunk pchunk ^ prow of its row and stores it at LDS chunk position pchunk (source-side swizzle)
+  const int prow = lane >> 3, pchunk = lane & 7;
+  const unsigned wA = base + (wave * 64 + prow) * 128 + pchunk * 16, wW = wA + 32768;
+  const unsigned voffA0 = (unsigned)(prow * g.lda * sizeof(T)) + ((pchunk ^ prow) << 4);
+  const unsigned voffW0 = (unsigned)(prow * (long)g.K * sizeof(T)) + ((pchunk ^ prow) << 4);
+
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    int bid = xcd_remap(vb, nwg);
+    const int GM = g.group_m > 0 ? g.group_m : 4;
+    const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
+    const int gm = min(GM, tiles_m - grp * GM);
+    const int tm = grp * GM + rem % gm, tn = rem / gm;
+    const int m0 = tm << 8, n0 = tn << 8;
+    const char* sb[16];  // SGPR bases of the 16 staged row groups (8 rows each): A rows m0 + wave*64 + 8 i, W rows n0 + wave*64 + 8 i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sb[i] = uniform_ptr((const char*)g.A + (long)(m0 + wave * 64 + i * 8) * g.lda * sizeof(T));
+      sb[8 + i] = uniform_ptr((const char*)g.W + (long)(n0 + wave * 64 + i * 8) * g.K * sizeof(T));
+    }
+    f32x4 stage[16];
+    unsigned voffA = voffA0, voffW = voffW0;  // advance by 128 B per K tile
+    auto gload = [&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      stage[J] = global_load16_nw(sb[J], J < 8 ? voffA : voffW);
+    };
+    auto swrite = [&](auto jj, unsigned bo) {
+      constexpr int J = decltype(jj)::value;
+      if constexpr (J < 8) lds_write16_nw<J * 1024>(wA + bo, stage[J]);
+      else lds_write16_nw<(J - 8) * 1024>(wW + bo, stage[J]);
+    };
+    f32x4 acc[8][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][8], fwx[2];
+    auto read_a = [&](auto rr, auto kk, unsigned bo) {  // A fragment row block R of k-step KS
+      constexpr int R = decltype(rr)::value, KS = decltype(kk)::value;
+      fa[KS][R] = lds_read16_nw<R * 2048>((KS ? aA1 : aA0) + bo);
+    };
+    auto read_w = [&](auto rr, auto kk, auto slot, unsigned bo) {  // W fragment row block R of k-step KS into fwx[SLOT]
+      constexpr int R = decltype(rr)::value, KS = decltype(kk)::value, S = decltype(slot)::value;
+      fwx[S] = lds_read16_nw<R * 2048>((KS ? aW1 : aW0) + bo);
+    };
+
+    // K offsets of the staged loads are clamped to the last tile: past the end of K the pipeline keeps running on a
+    // harmless re-load of tile nk - 1 (nothing reads it), so the loop body carries no "is there a next tile" branch.
+    const unsigned kmax = (unsigned)(nk - 1) * 128;
+    unsigned koff = 0;
+    auto advance = [&]() { koff = min(koff + 128u, kmax); voffA = voffA0 + koff; voffW = voffW0 + koff; };
+    __syncthreads();  // the previous tile's last fragment reads are done before this tile's first writes land
+    static_for<0, 16>([&](auto j) { gload(j); });
+    advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, 16>([&](auto j) { swrite(j, 0u); });
+    static_for<0, 16>([&](auto j) { gload(j); });
+    advance();
+    lds_wait<0>();
+    __builtin_amdgcn_s_barrier();
+    static_for<0, 8>([&](auto r) { read_a(r, I0{}, 0u); });
+    read_w(I0{}, I0{}, I0{}, 0u);
+
+    // Invariant at the top of K tile kt: LDS buffer kt & 1 holds tile kt; `stage` holds tile kt + 1 (in flight); fa[0] = A
+    // fragments (kt, k-step 0); fwx[0] = W fragment (kt, k-step 0, row block 0).  LDS operations are waited for with
+    // COUNTED lgkmcnt: at a row block's start only its own W fragment (issued one row block earlier) must be back, the
+    // younger prefetches stay in flight.
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned bo = (kt & 1) * BUF, bn = bo ^ BUF;
+      // ---- phase 1: k-step 0.  Row blocks 0-3 also fetch the A fragments of k-step 1 (two each).
+      static_for<0, 8>([&](auto nn) {
+        constexpr int ni = decltype(nn)::value;
+        if constexpr (ni >= 1 && ni <= 4) lds_wait<2>(); else lds_wait<0>();
+        if constexpr (ni < 7) read_w(std::integral_constant<int, ni + 1>{}, I0{}, std::integral_constant<int, (ni + 1) & 1>{}, bo);
+        else read_w(I0{}, I1{}, I0{}, bo);  // first W fragment of k-step 1
+        static_for<0, 8>([&](auto mm) {
+          constexpr int mi = decltype(mm)::value;
+          mfma16_agpr(acc[ni][mi], fwx[ni & 1], fa[0][mi], T());
+          if constexpr (ni < 4 && (mi == 1 || mi == 5)) read_a(std::integral_constant<int, ni * 2 + (mi == 5)>{}, I1{}, bo);
+        });
+      });
+      // ---- phase 2: k-step 1.  Row blocks 0-3: the staged tile goes to the other LDS buffer (a store in every even MFMA
+      //      gap, the same register re-loaded two tiles ahead in the odd gap behind it); row block 4: barrier; row blocks
+      //      4-5: A fragments of the next tile's k-step 0.
+      static_for<0, 8>([&](auto nn) {
+        constexpr int ni = decltype(nn)::value;
+        if constexpr (ni >= 1 && ni <= 3) lds_wait<4>();
+        else if constexpr (ni == 5 || ni == 6) lds_wait<4>();
+        else lds_wait<0>();
+        if constexpr (ni == 0) __builtin_amdgcn_s_barrier();  // every wave is done reading buffer bn (tile kt - 1)
+        if constexpr (ni == 4) __builtin_amdgcn_s_barrier();  // tile kt + 1 is complete in bn
+        if constexpr (ni < 7) read_w(std::integral_constant<int, ni + 1>{}, I1{}, std::integral_constant<int, (ni + 1) & 1>{}, bo);
+        else read_w(I0{}, I0{}, I0{}, bn);  // first W fragment of the next tile
+        static_for<0, 8>([&](auto mm) {
+          constexpr int mi = decltype(mm)::value;
+          mfma16_agpr(acc[ni][mi], fwx[ni & 1], fa[1][mi], T());
+          if constexpr (ni < 4) {
+            constexpr int J = ni * 4 + mi / 2;
+            if constexpr ((mi & 1) == 0) {
+              // load J is the oldest of the 16 staged loads in flight (16 - J of the previous round, J re-issued in this one)
+              asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+              swrite(std::integral_constant<int, J>{}, bn);
+            } else {
+              gload(std::integral_constant<int, J>{});
+            }
+          }
+          if constexpr ((ni == 4 || ni == 5) && mi < 4) read_a(std::integral_constant<int, (ni - 4) * 4 + mi>{}, I0{}, bn);
+        });
+      });
+      advance();
+    }
+    // MFMA results settle before anything reads the accumulators: hipcc does not know the asm statements are MFMAs and
+    // would read (spill) the last tile's registers straight behind them -- the nops carry the last row block as operands
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
+                   "+a"(acc[7][6]), "+a"(acc[7][7])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int qm = 0; qm < 2; ++qm) {
+        f32x4 sub[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
+        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk);
+      }
+  }
+}
+
+// v4 takes a GEMM when its addressing is the plain one the staged loads assume
+template <int AMODE> static inline bool gemm_v4_ok(const GemmArgs& g, size_t es) {
+  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0 && g.a_rpg >= g.M &&
+         (long)g.lda * 2 * 8 < (1L << 31) && (long)g.K * 2 * 8 < (1L << 31);
+}
+
+#endif  // BSG_GEMM_V4
+
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 3;
@@ -626,6 +804,13 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   } else if (ver == 2 || g.N <= 192) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
+#ifdef BSG_GEMM_V4
+  } else if (ver == 4 && gemm_v4_ok<AMODE>(g, sizeof(T))) {
+    if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN) {
+      const int tiles = (g.M / 256) * (g.N / 256);
+      hipLaunchKernelGGL((gemm_nt_kernel_v4<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);
+    }
+#endif
   } else {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
     static const int persist = getenv("BSG_GEMM_PERSIST") ? atoi(getenv("BSG_GEMM_PERSIST")) : 256;  // workgroups in the persistent grid = CUs (0 = one workgroup per tile); 512: slower

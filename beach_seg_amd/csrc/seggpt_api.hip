@@ -148,6 +148,12 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
+#ifdef BSG_GEMM_V4
+  if constexpr (sizeof(T) == 2 && AM == A_PLAIN) {
+    static bool once4 = (allow_lds(gemm_nt_kernel_v4<T, EPI>, 131072), true);
+    (void)once4;
+  }
+#endif
   const bool plain_rows = AM == A_PLAIN && g.a_rpg <= 0;
   if (g.a_rpg <= 0) { g.a_rpg = AM == A_FEAT ? g.tokens : (g.M > 0 ? g.M : 1); g.a_gstride = 0; }
   static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
