@@ -85,8 +85,8 @@ def load():
     lib.bsg_profile_reset.argtypes = [vp]
     lib.bsg_op_gemm.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
     lib.bsg_tif_image.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
-    lib.bsg_train_aug.argtypes = [vp, i, i, i, vp, vp, vp, vp, f3, f3, vp, vp]
-    lib.bsg_train_aug_bwd.argtypes = [vp, i, i, i, vp, vp, f3, vp]
+    lib.bsg_train_aug.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, f3, f3, vp, vp, vp]
+    lib.bsg_train_aug_bwd.argtypes = [vp, i, i, i, vp, vp, vp, vp, f3, vp, vp]
     lib.bsg_confusion_update.argtypes = [vp, C.c_long, i, i, vp, vp, vp, vp]
     lib.bsg_op_attention_scratch_bytes.argtypes = [i, i, i]
     lib.bsg_op_attention_scratch_bytes.restype = sz

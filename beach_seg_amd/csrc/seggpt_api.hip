@@ -887,25 +887,46 @@ int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* b
 }
 
 int bsg_train_aug(void* stream, int batch, int h, int w, const float* img, const uint8_t* mask, const int32_t* params,
-                  const float* noise, const float mean[3], const float std[3], float* out, uint8_t* mask_out) {
+                  const float* color, const float* noise, const float mean[3], const float std[3], float* out,
+                  uint8_t* mask_out, float* scratch) {
   if (!img || !params || !out) return fail("bsg_train_aug: null argument");
   if ((mask == nullptr) != (mask_out == nullptr)) return fail("bsg_train_aug: mask and mask_out go together");
+  if (color && !scratch) return fail("bsg_train_aug: colour parameters need the scratch plane (batch*3*h*w floats)");
+  if (color && (h < 3 || w < 3)) return fail("bsg_train_aug: sharpness needs an image of at least 3x3 pixels");
   AugArgs a{};
-  a.img = img; a.mask = mask; a.params = (const int*)params; a.noise = noise; a.out = out; a.mask_out = mask_out;
+  a.img = img; a.mask = mask; a.params = (const int*)params; a.color = color; a.noise = noise; a.out = out;
+  a.mask_out = mask_out; a.tmp = scratch;
   a.B = batch; a.H = h; a.W = w;
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean[c]; a.istd[c] = 1.f / std[c]; }
   const long n = (long)batch * h * w;
-  hipLaunchKernelGGL(train_aug_fwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)std::min<long>((n + 255) / 256, 65535));
+  if (color) hipLaunchKernelGGL(train_aug_color_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(train_aug_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   CHECK_LAUNCH();
   return 0;
 }
 
-int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const int32_t* params, const float std[3],
-                      float* grad_img) {
+int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const float* img, const int32_t* params,
+                      const float* color, const float std[3], float* grad_img, float* scratch) {
   if (!grad_out || !params || !grad_img) return fail("bsg_train_aug_bwd: null argument");
   const long n = (long)batch * h * w;
-  hipLaunchKernelGGL(train_aug_bwd_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 65535)), dim3(256), 0, (hipStream_t)stream,
-                     grad_out, (const int*)params, grad_img, batch, h, w, 1.f / std[0], 1.f / std[1], 1.f / std[2]);
+  const dim3 grid((unsigned)std::min<long>((n + 255) / 256, 65535));
+  if (!color) {
+    hipLaunchKernelGGL(train_aug_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, grad_out, (const int*)params, grad_img,
+                       batch, h, w, 1.f / std[0], 1.f / std[1], 1.f / std[2]);
+    CHECK_LAUNCH();
+    return 0;
+  }
+  if (!img || !scratch) return fail("bsg_train_aug_bwd: colour parameters need img and the scratch planes (2*batch*3*h*w floats)");
+  AugArgs f{};
+  f.img = img; f.params = (const int*)params; f.color = color; f.tmp = scratch; f.B = batch; f.H = h; f.W = w;
+  hipLaunchKernelGGL(train_aug_color_kernel, grid, dim3(256), 0, (hipStream_t)stream, f);
+  AugBwdArgs a{};
+  a.gout = grad_out; a.img = img; a.params = (const int*)params; a.color = color; a.tmp = scratch; a.g2 = scratch + 3 * n;
+  a.gin = grad_img; a.B = batch; a.H = h; a.W = w;
+  for (int c = 0; c < 3; ++c) a.istd[c] = 1.f / std[c];
+  hipLaunchKernelGGL(train_aug_sharp_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(train_aug_color_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   CHECK_LAUNCH();
   return 0;
 }

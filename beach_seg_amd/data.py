@@ -46,14 +46,18 @@ def tif_image(bands: np.ndarray, nodata: np.ndarray | None = None) -> np.ndarray
     return (np.moveaxis(ch, 0, -1) * 255).astype(np.uint8)
 
 
-def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, generator: torch.Generator | None = None
-                            ) -> tuple[torch.Tensor, torch.Tensor | None]:
+def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, generator: torch.Generator | None = None,
+                            with_color: bool = False):
     """Random parameters of the train-time augmentation chain (`src/data.py:195-224`), drawn on the host from an explicit
     generator (kornia draws them internally; kornia is not installable here, so the DISTRIBUTIONS follow kornia's
     documented parameter generators and the draw order is this function's own: "parity unpinned"):
       vertical / horizontal flip ~ Bernoulli(p);  erasing ~ Bernoulli(erasing_p) with area fraction ~ U(erasing_scale),
-      log-uniform aspect ratio in (0.3, 3.3), box placed uniformly inside the image;  noise ~ Bernoulli(gauss_p).
-    Returns (params i32 (B,5) = [flags, ex0, ey0, ew, eh], noise f32 (B,3,h,w) or None)."""
+      log-uniform aspect ratio in (0.3, 3.3), box placed uniformly inside the image;  noise ~ Bernoulli(gauss_p);
+      with_color: ColorJiggle (p = 1) brightness / contrast / saturation factors ~ U(max(0, 1 - a), 1 + a), hue factor ~
+      U(-hue, hue) (turns), ONE random order of the four operations per batch;  RandomSharpness ~ Bernoulli(sharpness_p)
+      with factor ~ U(0, sharpness).
+    Returns (params i32 (B,5) = [flags, ex0, ey0, ew, eh], noise f32 (B,3,h,w) or None) and, with_color, a third item
+    color f32 (B,6) = [brightness, contrast, saturation, hue, sharpness factor, order code] (flags bits 3 / 4 set)."""
     import math
 
     g = generator
@@ -69,18 +73,100 @@ def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, 
     ex = (u(batch) * (w - ew + 1).float()).floor().int()
     ey = (u(batch) * (h - eh + 1).float()).floor().int()
     zero = torch.zeros_like(ew)
-    params = torch.stack([flags, torch.where(erase, ex, zero), torch.where(erase, ey, zero), torch.where(erase, ew, zero),
-                          torch.where(erase, eh, zero)], dim=1).to(torch.int32).contiguous()
     noise = None
     if bool(do_noise.any()):
         noise = torch.randn(batch, 3, h, w, generator=g) * config.gauss_std + config.gauss_mean
-    return params, noise
+    color = None
+    if with_color:
+        def around_one(a):
+            lo, hi = max(0.0, 1.0 - a), 1.0 + a
+            return lo + u(batch) * (hi - lo)
+
+        order = torch.randperm(4, generator=g)
+        code = float(sum(int(o) << (2 * k) for k, o in enumerate(order)))
+        sharp_on = u(batch) < config.sharpness_p
+        color = torch.stack([around_one(config.brightness), around_one(config.contrast), around_one(config.saturation),
+                             (u(batch) * 2 - 1) * config.hue, u(batch) * config.sharpness, torch.full((batch,), code)],
+                            dim=1).float().contiguous()
+        flags |= (sharp_on.int() << 3) | 16
+    params = torch.stack([flags, torch.where(erase, ex, zero), torch.where(erase, ey, zero), torch.where(erase, ew, zero),
+                          torch.where(erase, eh, zero)], dim=1).to(torch.int32).contiguous()
+    return (params, noise, color) if with_color else (params, noise)
+
+
+def _rgb_to_hsv(x: torch.Tensor) -> torch.Tensor:
+    """kornia.color.rgb_to_hsv on one (3,H,W) image: h in [0, 2 pi), s, v."""
+    import math
+
+    mx, imax = x.max(0)
+    mn = x.min(0)[0]
+    dc = mx - mn
+    s = dc / (mx + 1e-8)
+    dc = torch.where(dc == 0, torch.ones_like(dc), dc)
+    rc, gc, bc = (mx[None] - x).unbind(0)
+    hs = torch.stack([bc - gc, (rc - bc) + 2.0 * dc, (gc - rc) + 4.0 * dc]) / dc[None]
+    h = torch.gather(hs, 0, imax[None])[0]
+    h = (h / 6.0) % 1.0
+    return torch.stack([2.0 * math.pi * h, s, mx])
+
+
+def _hsv_to_rgb(x: torch.Tensor) -> torch.Tensor:
+    import math
+
+    h, s, v = x[0] / (2 * math.pi), x[1], x[2]
+    hi = torch.floor(h * 6) % 6
+    f = ((h * 6) % 6) - hi
+    p, q, t = v * (1.0 - s), v * (1.0 - f * s), v * (1.0 - (1.0 - f) * s)
+    hi = hi.long()
+    idx = torch.stack([hi, hi + 6, hi + 12])
+    table = torch.stack((v, q, p, p, t, v, t, v, v, q, p, p, p, p, t, v, v, q))
+    return torch.gather(table, 0, idx)
+
+
+def _color_jiggle(x: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """kornia.augmentation.ColorJiggle.apply_transform on one image with explicit factors c = [brightness, contrast,
+    saturation, hue, -, order code] (kornia.enhance.adjust_brightness(f - 1) / adjust_contrast / adjust_saturation /
+    adjust_hue(2 pi f), applied in the coded order)."""
+    import math
+
+    order = int(c[5])
+    for k in range(4):
+        op = (order >> (2 * k)) & 3
+        if op == 0:
+            x = (x + (float(c[0]) - 1.0)).clamp(0, 1)
+        elif op == 1:
+            x = (x * float(c[1])).clamp(0, 1)
+        else:
+            hsv = _rgb_to_hsv(x)
+            if op == 2:
+                hsv = torch.stack([hsv[0], (hsv[1] * float(c[2])).clamp(0, 1), hsv[2]])
+            else:
+                hsv = torch.stack([torch.fmod(hsv[0] + float(c[3]) * 2 * math.pi, 2 * math.pi), hsv[1], hsv[2]])
+            x = _hsv_to_rgb(hsv)
+    return x
+
+
+def _sharpness(x: torch.Tensor, factor: float) -> torch.Tensor:
+    """kornia.enhance.sharpness on one (3,H,W) image: blend of the image with its clamped 3x3 [[1,1,1],[1,5,1],[1,1,1]]/13
+    blur (interior only), `_blend_one` rules for the clamp."""
+    import torch.nn.functional as F
+
+    k = (torch.tensor([[1.0, 1.0, 1.0], [1.0, 5.0, 1.0], [1.0, 1.0, 1.0]], dtype=x.dtype, device=x.device) / 13).view(1, 1, 3, 3)
+    d = F.conv2d(x[None], k.repeat(3, 1, 1, 1), groups=3)[0].clamp(0.0, 1.0)
+    inner = F.pad(torch.ones_like(d), [1, 1, 1, 1])
+    result = torch.where(inner == 1, F.pad(d, [1, 1, 1, 1]), x)
+    if factor == 0.0:
+        return result
+    if factor == 1.0:
+        return x
+    res = result + (x - result) * factor
+    return res if 0.0 < factor < 1.0 else res.clamp(0, 1)
 
 
 def train_aug_reference(img: torch.Tensor, mask: torch.Tensor | None, params: torch.Tensor, noise: torch.Tensor | None,
-                        mean=ml_util.IMAGE_MEAN, std=ml_util.IMAGE_STD):
+                        mean=ml_util.IMAGE_MEAN, std=ml_util.IMAGE_STD, color: torch.Tensor | None = None):
     """Plain-torch statement of what `ops.train_aug` computes (any device, autograd through torch): the test oracle of the
-    HIP kernel and the CPU fallback-free documentation of its semantics."""
+    HIP kernels and the documentation of their semantics."""
     out, mout = [], []
     for b in range(img.shape[0]):
         fl, ex, ey, ew, eh = (int(v) for v in params[b])
@@ -92,6 +178,10 @@ def train_aug_reference(img: torch.Tensor, mask: torch.Tensor | None, params: to
         if fl & 2:
             x = x.flip(-1)
             m = m.flip(-1) if m is not None else None
+        if color is not None and fl & 16:
+            x = _color_jiggle(x, color[b])
+        if color is not None and fl & 8:
+            x = _sharpness(x, float(color[b, 4]))
         if ew > 0 and eh > 0:
             keep = torch.ones_like(x[0])
             keep[ey:ey + eh, ex:ex + ew] = 0
@@ -232,17 +322,18 @@ class BeachSegDataModule:
         return out
 
     def train_aug(self, batch: dict) -> dict:
-        """`src/data.py:195-224` on the batch dict: flips (image and mask together), RandomErasing, Gaussian noise,
-        Normalize, on device with backward to `batch["image"]` (`ops.train_aug`).  ColorJiggle / RandomSharpness are
-        not built (kornia-internal formulas: "parity unpinned").  Random parameters come from `self.aug_generator`."""
+        """`src/data.py:195-224` on the batch dict: flips (image and mask together), ColorJiggle, RandomSharpness,
+        RandomErasing, Gaussian noise, Normalize, on device with backward to `batch["image"]` (`ops.train_aug`).  The two
+        colour operations follow kornia's published formulas ("parity unpinned": kornia is not installable here).  Random
+        parameters come from `self.aug_generator`."""
         from . import ops
 
         img = batch["image"]
         B, _, h, w = img.shape
-        params, noise = sample_train_aug_params(B, h, w, self.config, self.aug_generator)
+        params, noise, color = sample_train_aug_params(B, h, w, self.config, self.aug_generator, with_color=True)
         mask = batch.get("mask")
         out, mo = ops.train_aug(img, mask, params.to(img.device), noise.to(img.device) if noise is not None else None,
-                                self.mean, self.std)
+                                self.mean, self.std, color=color.to(img.device))
         res = dict(batch)
         res["image"] = out
         if mo is not None:

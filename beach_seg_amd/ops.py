@@ -278,17 +278,19 @@ def tif_image(bands: torch.Tensor, nodata: torch.Tensor | None = None) -> torch.
 
 class _TrainAugFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, mask, params, noise, mean, std):
+    def forward(ctx, img, mask, params, noise, mean, std, color):
         lib = N.load()
         B, _, h, w = img.shape
         img_c = img.detach().float().contiguous()
         out = torch.empty_like(img_c)
         mask_c = mask.to(torch.uint8).contiguous() if mask is not None else None
         mask_out = torch.empty_like(mask_c) if mask_c is not None else None
+        scratch = torch.empty_like(img_c) if color is not None else None
         with torch.cuda.device(img.device):
-            N.check(lib.bsg_train_aug(_stream(), B, h, w, _ptr(img_c), _ptr(mask_c), _ptr(params), _ptr(noise), _f3(mean),
-                                      _f3(std), _ptr(out), _ptr(mask_out)))
-        ctx.params, ctx.std, ctx.shape = params, std, (B, h, w)
+            N.check(lib.bsg_train_aug(_stream(), B, h, w, _ptr(img_c), _ptr(mask_c), _ptr(params), _ptr(color), _ptr(noise),
+                                      _f3(mean), _f3(std), _ptr(out), _ptr(mask_out), _ptr(scratch)))
+        ctx.params, ctx.std, ctx.shape, ctx.color = params, std, (B, h, w), color
+        ctx.img = img_c if color is not None else None  # the colour chain's Jacobian is evaluated at the input pixels
         ctx.mark_non_differentiable(*([mask_out] if mask_out is not None else []))
         return (out, mask_out) if mask_out is not None else (out, None)
 
@@ -298,24 +300,30 @@ class _TrainAugFn(torch.autograd.Function):
         B, h, w = ctx.shape
         g = gout.contiguous().float()
         gin = torch.empty_like(g)
+        scratch = torch.empty((2,) + tuple(g.shape), dtype=torch.float32, device=g.device) if ctx.color is not None else None
         with torch.cuda.device(g.device):
-            N.check(lib.bsg_train_aug_bwd(_stream(), B, h, w, _ptr(g), _ptr(ctx.params), _f3(ctx.std), _ptr(gin)))
-        return gin, None, None, None, None, None
+            N.check(lib.bsg_train_aug_bwd(_stream(), B, h, w, _ptr(g), _ptr(ctx.img), _ptr(ctx.params), _ptr(ctx.color),
+                                          _f3(ctx.std), _ptr(gin), _ptr(scratch)))
+        return gin, None, None, None, None, None, None
 
 
 def train_aug(img: torch.Tensor, mask: torch.Tensor | None, params: torch.Tensor, noise: torch.Tensor | None = None,
-              mean=IMAGE_MEAN, std=IMAGE_STD):
+              mean=IMAGE_MEAN, std=IMAGE_STD, color: torch.Tensor | None = None):
     """The train-time augmentation chain of `src/data.py:195-224` with explicit random parameters (`bsg_train_aug`):
     img f32 (B,3,h,w) in [0,1] (autograd-tracked: the stacked prompt Parameters), mask u8 (B,h,w) / (B,1,h,w) or None,
-    params i32 (B,5) from `data.sample_train_aug_params`, noise f32 (B,3,h,w) or None -> (normalised image, mask)."""
-    _need_gpu(img, mask, params, noise)
+    params i32 (B,5) and color f32 (B,6) or None from `data.sample_train_aug_params`, noise f32 (B,3,h,w) or None ->
+    (normalised image, mask).  color = [brightness, contrast, saturation, hue, sharpness factor, order code] switches on
+    ColorJiggle (params flag bit 4) and RandomSharpness (bit 3): kornia's published formulas, parity unpinned."""
+    _need_gpu(img, mask, params, noise, color)
     if params.dtype != torch.int32 or tuple(params.shape) != (img.shape[0], 5):
         raise ValueError("params must be int32 (B, 5)")
+    if color is not None and (color.dtype != torch.float32 or tuple(color.shape) != (img.shape[0], 6)):
+        raise ValueError("color must be float32 (B, 6)")
     m = mask
     if m is not None and m.dim() == 4:
         m = m[:, 0]
     out, mo = _TrainAugFn.apply(img, m, params.contiguous(), noise.contiguous() if noise is not None else None, tuple(mean),
-                                tuple(std))
+                                tuple(std), color.contiguous() if color is not None else None)
     if mo is not None and mask.dim() == 4:
         mo = mo[:, None]
     return out, mo

@@ -165,14 +165,21 @@ int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* b
 
 /* Train-time augmentation of src/data.py:195-224 with EXPLICIT random parameters (the reference draws them inside
  * kornia): per sample params[b] = {flags, ex0, ey0, ew, eh}, flags bit 0 = vertical flip, bit 1 = horizontal flip, bit 2 =
- * add `noise` (f32 (B,3,h,w), already scaled by gauss_std and shifted by gauss_mean), the e* box is erased to 0 (ew = 0:
- * none); order flips -> erase -> noise -> Normalize.  ColorJiggle / RandomSharpness are not built.  img f32 (B,3,h,w) in
- * [0,1] -> out; mask u8 (B,h,w) -> mask_out follows the flips only (both NULL to skip).  bsg_train_aug_bwd is the
- * gradient wrt img (the learnable prompt pixels, src/model.py:197-205). */
+ * add `noise` (f32 (B,3,h,w), already scaled by gauss_std and shifted by gauss_mean), bit 3 = RandomSharpness applied,
+ * bit 4 = ColorJiggle applied; the e* box is erased to 0 (ew = 0: none).  color (NULL: neither colour operation): f32
+ * (B,6) = {brightness, contrast, saturation, hue factor (in turns, kornia's hue_factor), sharpness factor, order code}
+ * with order code = i0 | i1<<2 | i2<<4 | i3<<6, operation i0 first (0 brightness, 1 contrast, 2 saturation, 3 hue).
+ * Order: flips -> ColorJiggle -> RandomSharpness -> erase -> noise -> Normalize.  The two colour operations follow
+ * kornia's published definitions (kornia.enhance.adjust_brightness / adjust_contrast / adjust_saturation / adjust_hue /
+ * sharpness); kornia is not installable here, so they are "parity unpinned".  img f32 (B,3,h,w) in [0,1] -> out; mask u8
+ * (B,h,w) -> mask_out follows the flips only (both NULL to skip).  scratch: batch*3*h*w floats (forward) / twice that
+ * (backward), only with color.  bsg_train_aug_bwd is the gradient wrt img (the learnable prompt pixels,
+ * src/model.py:197-205); it needs the forward's img when color is given. */
 int bsg_train_aug(void* stream, int batch, int h, int w, const float* img, const uint8_t* mask, const int32_t* params,
-                  const float* noise, const float mean[3], const float std[3], float* out, uint8_t* mask_out);
-int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const int32_t* params,
-                      const float std[3], float* grad_img);
+                  const float* color, const float* noise, const float mean[3], const float std[3], float* out,
+                  uint8_t* mask_out, float* scratch);
+int bsg_train_aug_bwd(void* stream, int batch, int h, int w, const float* grad_out, const float* img, const int32_t* params,
+                      const float* color, const float std[3], float* grad_img, float* scratch);
 
 /* State update of MulticlassF1Score(num_classes=K, ignore_index) (src/model.py:85-93, 256, 295): confmat[t][p] += 1 over
  * the n pixels whose target t != ignore_index (pass -1 for none); confmat u64 [K][K], K <= 16; pred as i64 or u8 (the

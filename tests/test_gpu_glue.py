@@ -89,6 +89,48 @@ def test_train_aug_kernel_forward_and_backward_vs_torch():
     assert torch.allclose(out2.cpu(), ref2, rtol=1e-6, atol=1e-6)
 
 
+def test_train_aug_color_jiggle_and_sharpness_vs_torch():
+    """ColorJiggle + RandomSharpness inside the device augmentation chain (`bsg_train_aug` with colour parameters) against the
+    torch statement of kornia's published formulas (`data.train_aug_reference`; kornia itself is not installable here:
+    parity unpinned), forward and the gradient wrt the prompt pixels, for every operation order class, factors on both
+    sides of 1 (the clamps engage), a hue shift that wraps, sharpness factors inside and outside (0, 1), with and without
+    the operations per sample."""
+    g = torch.Generator().manual_seed(5)
+    B, h, w = 8, 24, 36
+    conf = BeachSegConfig(vertical_flip=0.5, horizontal_flip=0.5, erasing_p=0.5, gauss_p=0.5, erasing_scale=(0.05, 0.2),
+                          brightness=0.3, contrast=0.4, saturation=0.6, hue=0.4, sharpness=1.0, sharpness_p=0.6)
+    params, noise, color = sample_train_aug_params(B, h, w, conf, g, with_color=True)
+    perms = [(0, 1, 2, 3), (3, 2, 1, 0), (2, 0, 3, 1), (1, 3, 0, 2)]
+    for b in range(B):
+        color[b, 5] = float(sum(o << (2 * k) for k, o in enumerate(perms[b % 4])))
+    color[1, 4] = 1.7   # sharpening proper: the blend is clamped
+    color[2, 4] = 0.0   # the blurred image itself
+    params[1, 0] |= 8
+    params[2, 0] |= 8
+    params[3, 0] &= ~16  # no colour jiggle on this sample
+    params[4, 0] &= ~8
+    assert noise is not None
+    img = torch.rand(B, 3, h, w, generator=g)
+    img[5, :, :4] = img[5, :1, :4]  # grey pixels: zero chroma (the `deltac == 0` branch of rgb_to_hsv)
+    a = img.clone().requires_grad_(True)
+    ref, _ = train_aug_reference(a, None, params, noise, color=color)
+    gout = torch.randn(B, 3, h, w, generator=g)
+    (ref * gout).sum().backward()
+    b_ = img.to(DEV).requires_grad_(True)
+    out, _ = ops.train_aug(b_, None, params.to(DEV), noise.to(DEV), color=color.to(DEV))
+    (out * gout.to(DEV)).sum().backward()
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=2e-5)
+    # gradients: identical up to float rounding except where a clamp / hue sector boundary sits within rounding of the pixel
+    ga, gb = a.grad, b_.grad.cpu()
+    grey = torch.zeros(B, 3, h, w, dtype=torch.bool)
+    grey[5, :, :4] = True  # at zero chroma the max / min picks are ties: autograd's choice of winner is not defined
+    close = torch.isclose(gb, ga, rtol=1e-3, atol=1e-4) | grey
+    assert float(close.float().mean()) > 0.999, float(close.float().mean())
+    assert float((gb - ga)[~grey].norm() / ga[~grey].norm()) < 2e-2
+    with pytest.raises(ValueError):
+        ops.train_aug(b_, None, params.to(DEV), None, color=color[:, :5].to(DEV))
+
+
 def test_train_driver_end_to_end(tmp_path):
     """`beach_seg_amd.train.main` (src/train.py:71-122): prompt_batch.pt before != after, conf.yaml, classes.txt, and
     epochs = conf.epochs * 5 (the `len(dict)` quirk of src/train.py:98)."""

@@ -129,6 +129,35 @@ def test_train_aug_parameters_and_reference_semantics():
     assert torch.allclose(img.grad[0], g0.flip(-2)) and torch.allclose(img.grad[1], (torch.ones(3, 8, 10) / std))
 
 
+def test_train_aug_color_parameters_and_statement():
+    """The colour half of the sampler (ColorJiggle / RandomSharpness ranges of src/config.py:52-58 through kornia's documented
+    generators) and the torch statement of the two operations: identity factors are the identity, HSV round-trips, a half-turn
+    hue shift applied twice returns the image, sharpness factor 1 is the identity and factor 0 the blurred interior."""
+    from beach_seg_amd.data import _color_jiggle, _hsv_to_rgb, _rgb_to_hsv, _sharpness, sample_train_aug_params
+
+    conf = BeachSegConfig(sharpness_p=0.5)
+    params, noise, color = sample_train_aug_params(64, 16, 16, conf, torch.Generator().manual_seed(1), with_color=True)
+    p2, _ = sample_train_aug_params(64, 16, 16, conf, torch.Generator().manual_seed(1))
+    assert torch.equal(params[:, 1:], p2[:, 1:]) and torch.equal(params[:, 0] & 7, p2[:, 0])  # colour draws come last
+    assert color.shape == (64, 6) and bool((params[:, 0] & 16).all()) and 0 < int(((params[:, 0] >> 3) & 1).sum()) < 64
+    for k, a in enumerate((conf.brightness, conf.contrast, conf.saturation)):
+        assert float(color[:, k].min()) >= 1 - a and float(color[:, k].max()) <= 1 + a
+    assert float(color[:, 3].abs().max()) <= conf.hue and 0 <= float(color[:, 4].min()) and float(color[:, 4].max()) <= conf.sharpness
+    code = int(color[0, 5])
+    assert sorted((code >> (2 * k)) & 3 for k in range(4)) == [0, 1, 2, 3] and bool((color[:, 5] == code).all())
+    x = torch.rand(3, 12, 14, generator=torch.Generator().manual_seed(2))
+    assert torch.allclose(_hsv_to_rgb(_rgb_to_hsv(x)), x, atol=2e-6)
+    ident = torch.tensor([1.0, 1.0, 1.0, 0.0, 1.0, float(0 | 1 << 2 | 2 << 4 | 3 << 6)])
+    assert torch.allclose(_color_jiggle(x, ident), x, atol=2e-6)
+    half = torch.tensor([1.0, 1.0, 1.0, 0.5, 1.0, float(3 | 3 << 2 | 0 << 4 | 1 << 6)])  # hue + 0.5 turn, twice
+    assert torch.allclose(_color_jiggle(x, half), x, atol=5e-6)
+    assert torch.equal(_sharpness(x, 1.0), x)
+    blur = _sharpness(x, 0.0)
+    assert torch.equal(blur[:, 0], x[:, 0]) and torch.equal(blur[:, :, -1], x[:, :, -1])
+    want = (x[:, :3, :3].sum((1, 2)) + 4 * x[:, 1, 1]) / 13
+    assert torch.allclose(blur[:, 1, 1], want, atol=1e-6)
+
+
 def test_tif_image_eight_band_and_uint16(golden_dir):
     rec = np.load(golden_dir / "frontend_pil.npz")
     assert np.array_equal(tif_image(rec["tif8_bands"], rec["tif8_nodata"]), rec["tif8_rgb"])  # reference's own output
