@@ -62,8 +62,32 @@ class Accumulator:
         for group in _non_overlapping_groups(crops):
             ops.vote_paste(self.current_pred_counter, masks[group], crops[group].to(self.device), crop_size)
 
+    def reduce_votes(self, process_group=None) -> None:
+        """Multi-GPU predict (SURVEY.md section 8 e: windows sharded by index, replicas of the network): sum the ranks'
+        vote counters once, before the arg-max.  uint8 addition wraps at 256 on every backend, exactly like the single
+        process's `+= 1` (`src/predict.py:150-159`), so the reduced mosaic is bit-identical to the unsharded one."""
+        reduce_vote_counters(self.current_pred_counter, process_group)
+
     def result(self) -> torch.Tensor:
         return ops.vote_argmax(self.current_pred_counter)
+
+
+def reduce_vote_counters(counter: torch.Tensor, process_group=None) -> torch.Tensor:
+    """In-place SUM all-reduce of a u8 (H,W,K) vote counter over the ranks (modulo 256).  RCCL sums uint8 natively; under
+    gloo a device tensor is staged through the host (gloo cannot reduce device memory of a ROCm build)."""
+    import torch.distributed as dist
+
+    if counter.dtype != torch.uint8:
+        raise ValueError("vote counters are uint8")
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return counter
+    if counter.is_cuda and dist.get_backend(process_group) == "gloo":
+        h = counter.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=process_group)
+        counter.copy_(h)
+    else:
+        dist.all_reduce(counter, op=dist.ReduceOp.SUM, group=process_group)
+    return counter
 
 
 def crops_are_disjoint(crops: torch.Tensor) -> bool:
@@ -100,12 +124,17 @@ def _non_overlapping_groups(crops: torch.Tensor) -> list[torch.Tensor]:
 @torch.no_grad()
 def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Tensor, crops: torch.Tensor,
                    out_shape: tuple[int, int], crop_size: int, batch_size: int = 64, date: str = "d0",
-                   use_graph: bool = False) -> torch.Tensor:
+                   use_graph: bool = False, rank: int = 0, world: int = 1, process_group=None) -> torch.Tensor:
     """Sliding-window inference (BASELINE config 4): images f32 (n,3,S,S) normalised, one prompt per crop_idx.
     Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`).
-    `use_graph`: replay the network forward from one captured hipGraph (full batches only; the tail runs eagerly)."""
+    `use_graph`: replay the network forward from one captured hipGraph (full batches only; the tail runs eagerly).
+    `world` > 1: this rank takes windows rank, rank + world, ... (every rank is a replica of the network), the vote
+    counters are summed once at the end and every rank returns the full mosaic -- bit-identical to world = 1."""
     acc = Accumulator(out_shape, model.conf.classes, model.device)
     disjoint = crops_are_disjoint(crops)  # decided once per mosaic: no host round trip per batch of windows
+    if world > 1:
+        images, crop_idx, crops = images[rank::world], crop_idx[rank::world], crops[rank::world]
+    acc.initialize_current(date)  # a rank without windows still joins the reduction with an all-zero counter
     crops_dev = crops.to(model.device)
     graphed = model.model.capture_forward(batch_size) if use_graph and images.shape[0] >= batch_size else None
     for s in range(0, images.shape[0], batch_size):
@@ -119,6 +148,8 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
         else:
             pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
         acc.update(date, crops_dev[sl] if disjoint else crops[sl], pred.to(torch.uint8), crop_size, disjoint=disjoint)
+    if world > 1:
+        acc.reduce_votes(process_group)
     return acc.result()
 
 

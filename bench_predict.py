@@ -3,12 +3,16 @@
 over a synthetic mosaic, 1 GPU, network forward replayed from a captured hipGraph, votes accumulated on device.
 
     python bench_predict.py [--size 8192] [--batch 64] [--crop 112]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_predict.py   # N replicas
+
+With N > 1 ranks every GPU holds a replica of the network, takes windows rank, rank + N, ... and the uint8 vote counters are
+summed once at the end (`Accumulator.reduce_votes`, RCCL): SURVEY.md section 8 (e), inference.
 
 The reference's loop (`src/predict.py:232-262`) runs batch_size 1 on the CPU; here the 5,476 windows of an
 8192 x 8192 mosaic are cut (zero-padded at the edges), resized to 448 x 448 with Pillow-exact BICUBIC and normalised on
 device (`ops.tile_frontend`), pushed through the ViT-L forward in batches, decoded, nearest-resized and voted without
 leaving the GPU."""
-import argparse, json, sys, time
+import argparse, json, os, sys, time
 from pathlib import Path
 import torch
 import torch.nn.functional as F
@@ -27,7 +31,12 @@ def main():
     ap.add_argument("--prompts", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     a = ap.parse_args()
-    dev = torch.device("cuda:0")
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     conf = BeachSegConfig(checkpoint="synthetic:vit_large", precision="bf16-true", crop_size=a.crop, batch_size=a.batch)
     pm = PromptModel(conf, device=dev)
     g = torch.Generator(device=dev).manual_seed(11)
@@ -36,15 +45,21 @@ def main():
                                  "mask": torch.randint(0, 4, (S, S), device=dev, generator=g, dtype=torch.uint8),
                                  "nodata": torch.zeros(S, S, dtype=torch.bool)} for i in range(a.prompts)])
     mosaic = (torch.rand(a.size // 64, a.size // 64, 3, device=dev, generator=g).repeat_interleave(64, 0).repeat_interleave(64, 1) * 255).to(torch.uint8)
-    crops = grid_crops(a.size, a.size, a.crop)
+    crops_all = grid_crops(a.size, a.size, a.crop)
+    n_all = crops_all.shape[0]
+    order = torch.arange(n_all)[rank::world]  # this rank's windows
+    crops = crops_all[order]
     n = crops.shape[0]
     graphed = None if a.no_graph else pm.model.capture_forward(a.batch)
     acc = Accumulator((a.size, a.size), conf.classes, dev)
+    acc.initialize_current("d0")
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize(); t0 = time.perf_counter(); t_net = 0.0
     for s in range(0, n, a.batch):
         cb = crops[s:s + a.batch]
         img = ops.tile_frontend(mosaic, cb.to(dev), a.crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
-        idx = torch.arange(s, s + img.shape[0]) % a.prompts
+        idx = order[s:s + img.shape[0]] % a.prompts
         pal, pal_norm = pm.create_palette(img.shape[0], train=True)
         pb, pmasks = pm.prepare_prompt(idx, pal, train=False)
         if graphed is not None and img.shape[0] == a.batch:
@@ -53,10 +68,21 @@ def main():
             out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
         pred = pm.process_pred_masks(out, pal_norm)
         acc.update("d0", cb, pred.to(torch.uint8), a.crop)
+    if world > 1:
+        acc.reduce_votes()
     result = acc.result()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank:
+            return
+    n = n_all
     print(json.dumps({"config": f"predict sliding window {a.size}x{a.size}, crop {a.crop}, batch {a.batch}, hipGraph={not a.no_graph}",
-                      "tiles": n, "seconds": round(dt, 3), "tiles_per_s": round(n / dt, 1), "fwd_ms_per_tile": round(dt / n * 1e3, 3),
+                      "n_gpus": world, "tiles": n, "seconds": round(dt, 3), "tiles_per_s": round(n / dt, 1), "fwd_ms_per_tile": round(dt / n * 1e3, 3),
                       "inference_tflops": round(n / dt * 1.5897, 1), "classes_present": torch.unique(result).tolist()}))
 
 

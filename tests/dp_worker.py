@@ -46,12 +46,46 @@ def run(world: int, rank: int) -> dict:
             "steps": eng.steps.cpu(), "loss": torch.stack(losses).cpu(), "mean_loss": mean_loss.cpu(), "confmat": cm.cpu()}
 
 
+def run_predict(world: int, rank: int) -> dict:
+    """Sharded sliding-window predict (`predict.predict_mosaic(rank=, world=)`): overlapping windows (stride < crop, so votes
+    from different ranks land on the same pixels), a window count that does not divide by the world size.  The palette is
+    pinned to the fixed one (`create_palette(train=False)`): `PromptModel.forward` draws a RANDOM palette per batch like the
+    reference, so two partitions of the windows consume the generator differently and are comparable only without it."""
+    import numpy as np
+
+    from beach_seg_amd.config import BeachSegConfig
+    from beach_seg_amd.model import PromptModel
+    from beach_seg_amd.predict import grid_crops, predict_mosaic
+    from beach_seg_amd.seggpt import SegGptNative
+    from beach_seg_amd.weights import SegGptGeometry, synth_state_dict
+
+    dev = torch.device("cuda:0")
+    geo = SegGptGeometry.tiny()
+    net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=dev, dtype=torch.float32)
+    conf = BeachSegConfig(batch_size=4, checkpoint="synthetic:tiny", precision="32-true", inpt_size=64, crop_size=16)
+    pm = PromptModel(conf, model=net)
+    gen = torch.Generator().manual_seed(5)
+    pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, 64, 64, generator=gen).numpy(),
+                                 "mask": torch.randint(0, 4, (64, 64), generator=gen, dtype=torch.uint8).numpy(),
+                                 "nodata": np.zeros((64, 64), bool)} for i in range(3)])
+    draw = pm.create_palette
+    pm.create_palette = lambda n, train: draw(n, False)
+    crops = grid_crops(40, 56, 16, stride=8)  # 5 x 7 = 35 windows
+    n = crops.shape[0]
+    images = torch.randn(n, 3, 64, 64, generator=gen)
+    crop_idx = torch.randint(0, 3, (n,), generator=gen)
+    mosaic = predict_mosaic(pm, images, crop_idx, crops, (40, 56), 16, batch_size=4, rank=rank, world=world)
+    torch.cuda.synchronize()
+    return {"mosaic": mosaic.cpu()}
+
+
 if __name__ == "__main__":
     import torch.distributed as dist
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     out = run(world, rank)
+    out.update(run_predict(world, rank))
     torch.save(out, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()

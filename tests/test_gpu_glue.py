@@ -198,3 +198,6 @@ def test_two_process_data_parallel_step_on_one_gpu(tmp_path):
     assert torch.equal(single["steps"], r0["steps"])
     assert abs(float(single["loss"].mean()) - float((r0["loss"] + r1["loss"]).mean() / 2)) < 1e-6 * abs(float(single["loss"].mean()))
     assert torch.equal(r0["confmat"], single["confmat"]) and abs(float(r0["mean_loss"]) - float(single["mean_loss"])) < 1e-6
+    # sharded predict (SURVEY section 8 e, inference): both ranks hold the full mosaic, bit-identical to one process
+    one = dp_worker.run_predict(world=1, rank=0)["mosaic"]
+    assert torch.equal(r0["mosaic"], one) and torch.equal(r1["mosaic"], one) and len(one.unique()) > 1

@@ -189,6 +189,13 @@ def _dp_worker(rank, world, port, q):
     cm[1, 1], cm[2, 3] = 3 + rank, 5
     mean_loss, cm_all = reduce_metrics(torch.tensor(2.0 * (rank + 1)), 2, cm)
     assert abs(float(mean_loss) - (2.0 + 4.0) / 4) < 1e-12 and cm_all[1, 1] == 7 and cm_all[2, 3] == 10 and int(cm_all.sum()) == 17
+    # the inference-side collective (SURVEY section 8 e): per-rank u8 vote counters summed once, wrapping at 256 like `+= 1`
+    from beach_seg_amd.predict import reduce_vote_counters
+    votes = torch.zeros(3, 4, 2, dtype=torch.uint8)
+    votes[0, 0, 0], votes[1, 2, 1], votes[2, 3, 0] = 200 + rank, 7 * rank, 255
+    reduce_vote_counters(votes)
+    assert int(votes[0, 0, 0]) == (200 + 201) % 256 and int(votes[1, 2, 1]) == 7 and int(votes[2, 3, 0]) == (255 + 255) % 256
+    assert int(votes.sum()) == 145 + 7 + 254
     q.put((rank, flat.clone()))
     dist.barrier()
     dist.destroy_process_group()
