@@ -77,15 +77,27 @@ def torch_apply_mask_rgb(palette: torch.Tensor, input: torch.Tensor) -> torch.Te
     return rgb.permute(0, 3, 1, 2).to(dtype=torch.float32) / 255.0
 
 
+_CONST_CACHE: dict = {}
+
+
+def mean_std(device, dtype=torch.float32) -> tuple[torch.Tensor, torch.Tensor]:
+    """ImageNet mean / std as (1,3,1,1) tensors, cached per (device, dtype): building them with `torch.tensor(...,
+    device=cuda)` is a pageable host-to-device copy that blocks the host until the stream has drained -- once per call
+    in the predict loop, that serialised the host behind every batch's forward."""
+    key = (str(device), dtype)
+    if key not in _CONST_CACHE:
+        _CONST_CACHE[key] = (torch.tensor(IMAGE_MEAN, dtype=dtype, device=device).view(1, 3, 1, 1),
+                             torch.tensor(IMAGE_STD, dtype=dtype, device=device).view(1, 3, 1, 1))
+    return _CONST_CACHE[key]
+
+
 def normalize(x: torch.Tensor) -> torch.Tensor:
     """`BeachSegDataModule.normalize` (`src/data.py:345-346`)."""
-    mean = torch.tensor(IMAGE_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-    std = torch.tensor(IMAGE_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+    mean, std = mean_std(x.device, x.dtype)
     return (x - mean) / std
 
 
 def denormalize(x: torch.Tensor) -> torch.Tensor:
     """`src/data.py:342-343`."""
-    mean = torch.tensor(IMAGE_MEAN, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-    std = torch.tensor(IMAGE_STD, dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+    mean, std = mean_std(x.device, x.dtype)
     return x * std + mean

@@ -137,22 +137,43 @@ class PromptModel(torch.nn.Module):
         self.prompt_batch["image"] = params
 
     # ---- src/model.py:215-231
-    def create_palette(self, batch_size: int, train: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    def _palette_host(self, batch_size: int, train: bool) -> torch.Tensor:
         if train:
-            pal = ml_util.generate_random_rgb_palette(self.num_classes, batch_size, "cpu", self.palette_g).to(self.device)
-        else:
-            p = torch.tensor(ml_util.build_palette(self.num_classes - 1), dtype=torch.uint8)
-            pal = torch.stack([p for _ in range(batch_size)]).to(self.device)
-        mean = torch.tensor(ml_util.IMAGE_MEAN, device=self.device)
-        std = torch.tensor(ml_util.IMAGE_STD, device=self.device)
-        pal_norm = (pal.to(torch.float32) / 255 - mean) / std
-        return pal, pal_norm
+            return ml_util.generate_random_rgb_palette(self.num_classes, batch_size, "cpu", self.palette_g)
+        p = torch.tensor(ml_util.build_palette(self.num_classes - 1), dtype=torch.uint8)
+        return torch.stack([p for _ in range(batch_size)])
+
+    def _palette_norm(self, pal: torch.Tensor) -> torch.Tensor:
+        mean, std = ml_util.mean_std(self.device)
+        return (pal.to(torch.float32) / 255 - mean.view(3)) / std.view(3)
+
+    def create_palette(self, batch_size: int, train: bool) -> tuple[torch.Tensor, torch.Tensor]:
+        pal = self._palette_host(batch_size, train).to(self.device)
+        return pal, self._palette_norm(pal)
+
+    def create_palettes(self, batch_sizes: list[int], train: bool) -> list[tuple[torch.Tensor, torch.Tensor]]:
+        """The palettes of a whole predict loop, drawn on the host in batch order (the same generator sequence as one
+        `create_palette` per batch) and uploaded ONCE: a per-batch upload is a blocking copy that keeps the host from
+        queueing batch i + 1 while batch i runs."""
+        if not batch_sizes:
+            return []
+        pal = torch.cat([self._palette_host(n, train) for n in batch_sizes]).to(self.device)
+        norm = self._palette_norm(pal)
+        out, s = [], 0
+        for n in batch_sizes:
+            out.append((pal[s:s + n], norm[s:s + n]))
+            s += n
+        return out
 
     # ---- src/model.py:177-213
     def prepare_prompt(self, batch_idxes, batch_palette: torch.Tensor, train: bool):
-        idx = batch_idxes.flatten().tolist() if isinstance(batch_idxes, torch.Tensor) else (
-            [batch_idxes] if isinstance(batch_idxes, int) else list(batch_idxes))
-        sel = torch.tensor(idx, device=self.device)
+        on_device = isinstance(batch_idxes, torch.Tensor) and batch_idxes.is_cuda and not torch.is_grad_enabled()
+        if on_device:  # predict loop: the indices already live on the device -- no host list, no upload, no sync
+            idx, sel = None, batch_idxes.flatten().long()
+        else:
+            idx = batch_idxes.flatten().tolist() if isinstance(batch_idxes, torch.Tensor) else (
+                [batch_idxes] if isinstance(batch_idxes, int) else list(batch_idxes))
+            sel = torch.tensor(idx, device=self.device)
         if torch.is_grad_enabled():
             image = torch.stack([self.prompt_batch["image"][i] for i in idx], dim=0)  # autograd-tracked stack
         else:  # inference (predict loop): one gather from a cached stack instead of B Parameter reads
@@ -166,7 +187,9 @@ class PromptModel(torch.nn.Module):
             image_n, mask = out["image"], out["mask"]
         else:
             image_n = self.normalize(image)
-        prompt_batch = {"image": image_n, "mask": mask, "crop_idx": self.prompt_batch["crop_idx"][torch.tensor(idx)]}
+        crop_idx = (self.prompt_batch["crop_idx"].to(self.device)[sel] if on_device
+                    else self.prompt_batch["crop_idx"][torch.tensor(idx)])
+        prompt_batch = {"image": image_n, "mask": mask, "crop_idx": crop_idx}
         prompt_color = self.normalize(ml_util.torch_apply_mask_rgb(batch_palette, mask))
         return prompt_batch, prompt_color
 

@@ -135,19 +135,27 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
     if world > 1:
         images, crop_idx, crops = images[rank::world], crop_idx[rank::world], crops[rank::world]
     acc.initialize_current(date)  # a rank without windows still joins the reduction with an all-zero counter
+    # everything the loop needs from the host goes up ONCE: a per-batch upload blocks the host until the stream has
+    # drained, i.e. until the previous batch's forward is done, and the GPU then idles through the host's share of a batch
     crops_dev = crops.to(model.device)
-    graphed = model.model.capture_forward(batch_size) if use_graph and images.shape[0] >= batch_size else None
-    for s in range(0, images.shape[0], batch_size):
-        sl = slice(s, s + batch_size)
-        n = images[sl].shape[0]
-        if graphed is not None and n == batch_size:
-            pal, pal_norm = model.create_palette(n, train=True)
-            prompt_batch, prompt_masks = model.prepare_prompt(crop_idx[sl], pal, train=False)
-            out = graphed(images[sl].to(model.device), prompt_batch["image"], prompt_masks)
+    idx_dev = crop_idx.to(model.device)
+    n_total = images.shape[0]
+    sizes = [min(batch_size, n_total - s) for s in range(0, n_total, batch_size)]
+    palettes = model.create_palettes(sizes, train=True)  # the reference draws a random palette per batch (src/model.py:138)
+    graphed = model.model.capture_forward(batch_size) if use_graph and n_total >= batch_size else None
+    with torch.no_grad():
+        for b, s in enumerate(range(0, n_total, batch_size)):
+            sl = slice(s, s + batch_size)
+            pal, pal_norm = palettes[b]
+            prompt_batch, prompt_masks = model.prepare_prompt(idx_dev[sl], pal, train=False)
+            img = images[sl].to(model.device)
+            if graphed is not None and sizes[b] == batch_size:
+                out = graphed(img, prompt_batch["image"], prompt_masks)
+            else:
+                out = model.model(pixel_values=img, prompt_pixel_values=prompt_batch["image"], prompt_masks=prompt_masks,
+                                  embedding_type="instance").pred_masks
             pred = model.process_pred_masks(out, pal_norm)
-        else:
-            pred = model({"image": images[sl], "crop_idx": crop_idx[sl]})
-        acc.update(date, crops_dev[sl] if disjoint else crops[sl], pred.to(torch.uint8), crop_size, disjoint=disjoint)
+            acc.update(date, crops_dev[sl] if disjoint else crops[sl], pred.to(torch.uint8), crop_size, disjoint=disjoint)
     if world > 1:
         acc.reduce_votes(process_group)
     return acc.result()

@@ -20,7 +20,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from beach_seg_amd import ml_util, ops  # noqa: F401
 from beach_seg_amd.config import BeachSegConfig
 from beach_seg_amd.model import PromptModel
-from beach_seg_amd.predict import Accumulator, grid_crops
+from beach_seg_amd.predict import Accumulator, crops_are_disjoint, grid_crops
 
 
 def main():
@@ -53,21 +53,27 @@ def main():
     graphed = None if a.no_graph else pm.model.capture_forward(a.batch)
     acc = Accumulator((a.size, a.size), conf.classes, dev)
     acc.initialize_current("d0")
+    # host data of the whole loop goes up once (per-batch uploads block the host behind the previous batch's forward)
+    crops_dev = crops.to(dev)
+    idx_dev = (order % a.prompts).to(dev)
+    sizes = [min(a.batch, n - s) for s in range(0, n, a.batch)]
+    disjoint = crops_are_disjoint(crops)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(); t0 = time.perf_counter(); t_net = 0.0
-    for s in range(0, n, a.batch):
-        cb = crops[s:s + a.batch]
-        img = ops.tile_frontend(mosaic, cb.to(dev), a.crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
-        idx = order[s:s + img.shape[0]] % a.prompts
-        pal, pal_norm = pm.create_palette(img.shape[0], train=True)
-        pb, pmasks = pm.prepare_prompt(idx, pal, train=False)
-        if graphed is not None and img.shape[0] == a.batch:
-            out = graphed(img, pb["image"], pmasks)
-        else:
-            out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
-        pred = pm.process_pred_masks(out, pal_norm)
-        acc.update("d0", cb, pred.to(torch.uint8), a.crop)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    palettes = pm.create_palettes(sizes, train=True)
+    with torch.no_grad():
+        for b, s in enumerate(range(0, n, a.batch)):
+            cb = crops_dev[s:s + a.batch]
+            img = ops.tile_frontend(mosaic, cb, a.crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
+            pal, pal_norm = palettes[b]
+            pb, pmasks = pm.prepare_prompt(idx_dev[s:s + a.batch], pal, train=False)
+            if graphed is not None and img.shape[0] == a.batch:
+                out = graphed(img, pb["image"], pmasks)
+            else:
+                out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
+            pred = pm.process_pred_masks(out, pal_norm)
+            acc.update("d0", cb if disjoint else crops[s:s + a.batch], pred.to(torch.uint8), a.crop, disjoint=disjoint)
     if world > 1:
         acc.reduce_votes()
     result = acc.result()

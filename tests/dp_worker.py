@@ -49,7 +49,7 @@ def run(world: int, rank: int) -> dict:
 def run_predict(world: int, rank: int) -> dict:
     """Sharded sliding-window predict (`predict.predict_mosaic(rank=, world=)`): overlapping windows (stride < crop, so votes
     from different ranks land on the same pixels), a window count that does not divide by the world size.  The palette is
-    pinned to the fixed one (`create_palette(train=False)`): `PromptModel.forward` draws a RANDOM palette per batch like the
+    pinned to the fixed one (`create_palettes(train=False)`): `PromptModel.forward` draws a RANDOM palette per batch like the
     reference, so two partitions of the windows consume the generator differently and are comparable only without it."""
     import numpy as np
 
@@ -68,8 +68,8 @@ def run_predict(world: int, rank: int) -> dict:
     pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, 64, 64, generator=gen).numpy(),
                                  "mask": torch.randint(0, 4, (64, 64), generator=gen, dtype=torch.uint8).numpy(),
                                  "nodata": np.zeros((64, 64), bool)} for i in range(3)])
-    draw = pm.create_palette
-    pm.create_palette = lambda n, train: draw(n, False)
+    draw = pm.create_palettes
+    pm.create_palettes = lambda sizes, train: draw(sizes, False)
     crops = grid_crops(40, 56, 16, stride=8)  # 5 x 7 = 35 windows
     n = crops.shape[0]
     images = torch.randn(n, 3, 64, 64, generator=gen)
