@@ -1,6 +1,8 @@
 """Summarise rocprofv3 --pmc CSVs (run on the GPU box): per kernel family the per-launch HBM bytes
 (FETCH_SIZE x2 on gfx950 for wide coalesced reads, WRITE_SIZE), MFMA / LDS busy fractions and effective clock.
-usage: python tools/pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <dir_grbm> <out.json>"""
+usage: python tools/pmc_summary.py <dir_fetch> <dir_write> <dir_sq> <dir_grbm> <out.json> [<dir_issue>]
+The optional sixth argument is a pass over the instruction-issue counters (SQ_ACTIVE_INST_VALU / LDS / VMEM / SCA per wave
+cycle, VALU and LDS instructions per MFMA): what the waves of a kernel spend their issue slots on."""
 import collections, csv, glob, hashlib, json, pathlib, re, sys
 
 
@@ -28,6 +30,7 @@ def load(d):
     return agg, cnt, dur
 
 
+ia = load(sys.argv[6])[0] if len(sys.argv) > 6 else None
 fa, fc, fd = load(sys.argv[1]); wa, wc, wd = load(sys.argv[2]); sa, sc, sd = load(sys.argv[3]); ga, gc, gd = load(sys.argv[4])
 out = {}
 for k in sd:
@@ -42,6 +45,13 @@ for k in sd:
         "clock_GHz": ga[k]["GRBM_GUI_ACTIVE"] / 8 / max(gd[k], 1),
     }
     o = out[k]
+    if ia is not None and k in ia:
+        iw = ia[k]["SQ_WAVE_CYCLES"] or 1
+        mf = ia[k]["SQ_INSTS_MFMA"]
+        o.update({"active_inst_valu": ia[k]["SQ_ACTIVE_INST_VALU"] / iw, "active_inst_lds": ia[k]["SQ_ACTIVE_INST_LDS"] / iw,
+                  "active_inst_vmem": ia[k]["SQ_ACTIVE_INST_VMEM"] / iw, "active_inst_sca": ia[k]["SQ_ACTIVE_INST_SCA"] / iw,
+                  "valu_insts_per_mfma": (ia[k]["SQ_INSTS_VALU"] - mf) / mf if mf else None,
+                  "lds_insts_per_mfma": ia[k]["SQ_INSTS_LDS"] / mf if mf else None})
     o["hbm_GBps"] = (o["hbm_fetch_MB_per_launch"] + o["hbm_write_MB_per_launch"]) * 1e6 / (o["avg_us"] * 1e3) if o["avg_us"] else 0
 out["_meta"] = {"csrc_sha": csrc_sha(), "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE x1; one rocprofv3 --pmc pass per counter group"}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
