@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   __syncthreads();  // scratch reads done before any wave's DMA lands in the tile area
   if (q0 + col >= a.N) relh_g = a.relhT + sh * a.hp * npad + a.N - 1;  // clamped duplicate lanes read a valid column
   const float c2 = a.scale * 1.44269504088896340736f;
+  const float lazy_thr = 8.0f / c2;  // 2^8 in the exponent, in score units
   float m = -INFINITY, l = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -396,7 +397,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    if (__builtin_amdgcn_ballot_w64(mn > m)) {  // wave-uniform: skip the O rescale once the running max is stable
+    // Lazy reference maximum: the 34-multiply rescale of O and l runs only when some row of the wave overshoots its
+    // reference by more than 2^8 in the exponent (wave-uniform branch).  A new row maximum shows up at key tile t with
+    // probability ~1/t PER ROW, so with 32 rows per wave "rescale whenever any row has a new maximum" fired in ~85 % of
+    // the tiles; below the threshold P simply reaches up to 2^8 instead of 1 (fp32 sums; bf16 / f16 P operands have the
+    // range), and m stays a valid reference for lse2 = m c2 + log2(l).
+    if (__builtin_amdgcn_ballot_w64(mn > m + lazy_thr)) {
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * c2);
       l *= alpha;
 #pragma unroll
