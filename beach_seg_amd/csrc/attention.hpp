@@ -391,9 +391,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         mma32(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qf[ks]);
     }
     // online softmax over this lane's 32 slots (+ partner half-wave); padded key slots carry relw = -inf
-    float mx0 = st[0][0], mx1 = st[1][0];
+    float mx0 = -INFINITY, mx1 = -INFINITY;  // a constant seed: no canonicalising v_max of the first MFMA outputs
 #pragma unroll
-    for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, st[0][r]); mx1 = fmaxf(mx1, st[1][r]); }
+    for (int r = 0; r < 16; ++r) { mx0 = fmaxf(mx0, st[0][r]); mx1 = fmaxf(mx1, st[1][r]); }
     float mx = fmaxf(mx0 + rh[0], mx1 + rh[1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
