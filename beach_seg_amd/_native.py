@@ -21,7 +21,7 @@ SYMBOLS = (
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
     "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend", "bsg_decode_hf",
     "bsg_op_attention", "bsg_op_attention_scratch_bytes", "bsg_tif_image", "bsg_train_aug", "bsg_train_aug_bwd",
-    "bsg_confusion_update",
+    "bsg_confusion_update", "bsg_loss_fwd_bwd_ids", "bsg_mask_rgb_norm",
 )
 
 
@@ -71,6 +71,8 @@ def load():
     lib.bsg_loss_scratch_bytes.argtypes = [i, i]
     lib.bsg_loss_scratch_bytes.restype = sz
     lib.bsg_loss_fwd_bwd.argtypes = [vp, i, i, i, vp, vp, vp, f, i, vp, vp, vp, sz]
+    lib.bsg_loss_fwd_bwd_ids.argtypes = [vp, i, i, i, i, vp, vp, vp, f, i, vp, vp, vp, sz]
+    lib.bsg_mask_rgb_norm.argtypes = [vp, i, i, i, i, vp, vp, C.c_float * 3, C.c_float * 3, vp]
     lib.bsg_decode_argmin.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
     f3 = C.c_float * 3
     lib.bsg_prompt_gather.argtypes = [vp, i, i, i, vp, vp, f3, f3, vp]
@@ -90,7 +92,7 @@ def load():
     lib.bsg_confusion_update.argtypes = [vp, C.c_long, i, i, vp, vp, vp, vp]
     lib.bsg_op_attention_scratch_bytes.argtypes = [i, i, i]
     lib.bsg_op_attention_scratch_bytes.restype = sz
-    lib.bsg_op_attention.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz]
+    lib.bsg_op_attention.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz]
     _lib = lib
     return lib
 

@@ -112,7 +112,8 @@ __global__ void tif_map_kernel(TifArgs a) {
 // factor, order code} (only read when bit 3 / bit 4 is set; order code = i0 | i1 << 2 | i2 << 4 | i3 << 6, i0 applied first,
 // 0 brightness, 1 contrast, 2 saturation, 3 hue).
 // Order of src/data.py:195-224: flips -> ColorJiggle -> RandomSharpness -> erase box to 0 -> + noise -> Normalize.
-// mask_out (may be nullptr) follows the flips only (the intensity operations leave masks alone).
+// mask_out (may be nullptr) follows the flips (the intensity operations leave masks alone); with flags bit 5 the erased box
+// is also set to class 0 in the mask (what recent kornia does for masks under RandomErasing; parity unpinned, off by default).
 // ColorJiggle / RandomSharpness follow kornia's published definitions (kornia.enhance.adjust_* / sharpness; kornia is not
 // installed here: parity unpinned):
 //   brightness: clamp(x + (f - 1), 0, 1);  contrast: clamp(x f, 0, 1);  saturation: HSV, s <- clamp(s f, 0, 1);
@@ -245,7 +246,7 @@ __global__ void train_aug_fwd_kernel(AugArgs a) {
     const int fl = pr[0];
     const int ys = (fl & 1) ? a.H - 1 - y : y, xs = (fl & 2) ? a.W - 1 - x : x;
     const bool erased = aug_erased(pr, x, y);
-    if (a.mask_out) a.mask_out[i] = a.mask[(long)b * hw + (long)ys * a.W + xs];
+    if (a.mask_out) a.mask_out[i] = ((fl & 32) && erased) ? (uint8_t)0 : a.mask[(long)b * hw + (long)ys * a.W + xs];
     const bool interior = y > 0 && y < a.H - 1 && x > 0 && x < a.W - 1;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

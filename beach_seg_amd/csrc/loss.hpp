@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const float* __restri
                                                             const float* __restrict__ counts,
                                                             const unsigned long long* __restrict__ total,
                                                             float* __restrict__ dpred, float* __restrict__ partial,
-                                                            int B, int H, int W, float beta, int variant) {
+                                                            int B, int H, int W, float beta, int variant,
+                                                            const uint8_t* __restrict__ ids = nullptr,
+                                                            const float* __restrict__ lut = nullptr, int K = 0) {
   const long hw = (long)H * W, n = (long)B * 3 * 2 * hw;
   const float denom = 3.f * (float)(*total);
   const float inv = 1.f / denom;
@@ -42,7 +44,10 @@ __global__ __launch_bounds__(256) void loss_fwd_bwd_kernel(const float* __restri
       const int b = bc / 3;
       const float wgt = variant == 0 ? counts[p] : (yes[(long)b * hw + p] ? 1.f : 0.f);
       if (wgt != 0.f) {
-        const float d = pred[i] - labels[bc * hw + p];
+        // ids: the label image is never materialised -- its pixel IS lut[b][class id][c], the normalised palette entry
+        // (same bits as Normalize(torch_apply_mask_rgb(...)), src/model.py:238-239)
+        const float lab = ids ? lut[((long)b * K + min((int)ids[(long)b * hw + p], K - 1)) * 3 + (bc - 3 * b)] : labels[bc * hw + p];
+        const float d = pred[i] - lab;
         const float ad = fabsf(d);
         float l, dl;
         if (ad < beta) { l = 0.5f * d * d / beta; dl = d / beta; }
@@ -66,6 +71,40 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partial, int n,
   for (int i = threadIdx.x; i < n; i += 64) acc += partial[i];
   acc = wave_sum(acc);
   if (threadIdx.x == 0) loss[0] = acc / (3.f * (float)(*total));
+}
+
+// torch_apply_mask_rgb (+ Normalize) on device (src/util/ml_util.py:114-132, src/data.py:345; callers src/model.py:211-212,
+// 238-239): class ids u8 (B,H,W) + palette u8 (B,K,3) -> f32 (B,3,H,W) = (palette[b][id][c] / 255 - mean[c]) / std[c], every
+// step its own correctly rounded IEEE operation like torch's (mean 0 / std 1 gives the un-normalised [0,1] image exactly).
+// One block column per sample: the K x 3 table is formed once in LDS, then 4 pixels per thread (one u32 of ids, three
+// 16-byte stores).  HBM-bound: 13 bytes per pixel.
+__global__ __launch_bounds__(256) void mask_rgb_norm_kernel(const uint8_t* __restrict__ ids, const uint8_t* __restrict__ pal,
+                                                             float* __restrict__ out, long hw, int K, float m0, float m1,
+                                                             float m2, float s0, float s1, float s2) {
+  __shared__ float lut[3 * 256];
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < 3 * K; t += 256) {
+    const int k = t / 3, c = t - 3 * k;
+    const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, sd = c == 0 ? s0 : c == 1 ? s1 : s2;
+    lut[c * 256 + k] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)pal[((long)b * K + k) * 3 + c], 255.0f), mean), sd);
+  }
+  __syncthreads();
+  const uint8_t* src = ids + (long)b * hw;
+  float* dst = out + (long)b * 3 * hw;
+  const long nq = (hw & 3) ? 0 : hw >> 2;  // 4-pixel path needs 4-byte / 16-byte aligned planes
+  for (long q = blockIdx.x * 256L + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    const unsigned v = *(const unsigned*)(src + 4 * q);
+    const int i0 = min((int)(v & 255), K - 1), i1 = min((int)((v >> 8) & 255), K - 1), i2 = min((int)((v >> 16) & 255), K - 1),
+              i3 = min((int)(v >> 24), K - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      *(f32x4*)(dst + c * hw + 4 * q) = f32x4{lut[c * 256 + i0], lut[c * 256 + i1], lut[c * 256 + i2], lut[c * 256 + i3]};
+  }
+  if (blockIdx.x == 0)
+    for (long p = 4 * nq + threadIdx.x; p < hw; p += 256) {
+      const int i = min((int)src[p], K - 1);
+      for (int c = 0; c < 3; ++c) dst[c * hw + p] = lut[c * 256 + i];
+    }
 }
 
 // arg-min over K palette colours of sum_c (pred[c] - pal[k][c])^2 on the bottom half; first index wins ties.

@@ -134,13 +134,34 @@ __global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));  // non-negative floats order like uints
 }
-__global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ scale, int target_exp) {
+// state (int32, in the same workspace region, persistent across steps while the caller keeps the workspace): [0] overflow
+// flag of the LAST backward, [1] back-off exponent, [2] clean backwards since the last change, [3] overflows so far.
+__global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ scale, int target_exp,
+                                  int* __restrict__ state) {
   const float m = __builtin_bit_cast(float, absmax[0]);
   int k = 0;
-  if (m > 0.f && m < INFINITY) k = target_exp - (int)floorf(log2f(m));  // max |S * grad_pred| lands in [2^target, 2^(target+1))
+  // max |S * grad_pred| lands in [2^t, 2^(t+1)), t = target - back-off (the back-off grows when a backward overflowed)
+  if (m > 0.f && m < INFINITY) k = target_exp - state[1] - (int)floorf(log2f(m));
   k = max(-100, min(100, k));
   scale[0] = exp2f((float)k);
   scale[1] = exp2f((float)-k);
+  state[0] = 0;
+}
+// Overflow guard of the half-precision dgrad chain (what torch's GradScaler does on the host): any non-finite element of
+// the final prompt gradient raises state[0]; the caller skips its optimiser step (engine: the flag rides the gradient
+// all-reduce), and the next backward runs with 4x more headroom.  After 1000 clean backwards one bit is given back.
+__global__ void grad_finite_kernel(const float* __restrict__ g, long n4, int* __restrict__ state) {
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)g)[i];
+    const float s = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);  // 0 for finite values, NaN otherwise
+    bad |= !(s == 0.f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(state, 1);
+}
+__global__ void grad_state_kernel(int* __restrict__ state) {
+  if (state[0]) { state[1] = min(state[1] + 2, 14); state[2] = 0; state[3] += 1; }
+  else if (++state[2] >= 1000 && state[1] > 0) { state[1] -= 1; state[2] = 0; }
 }
 
 // ---------------------------------------------------------------------------------- canvas patch gather

@@ -125,7 +125,8 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
     p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
     if (m->c.embed_split) p.add("dx_split", -1, (size_t)B * (N / 2) * 3 * D * es);
-    p.add("gscale", -1, 256);  // f16: [S, 1/S] of the dgrad chain + the |grad_pred| max behind it
+    p.add("gscale", -1, 256);  // f16: f32 [0] S, [1] 1/S, [8] max |grad_pred| (bits); i32 [16] overflow flag of the last
+                               // backward, [17] back-off exponent, [18] clean backwards, [19] overflows so far
   }
   return p;
 }
@@ -445,7 +446,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return fail("memset failed");
       const long n4 = (long)B * 3 * H * W / 4;
       hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, dpred, n4, amax);
-      hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)amax, gscale, 8);
+      hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)amax, gscale, 8, (int*)(gscale + 16));
       CHECK_LAUNCH();
     }
     hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
@@ -567,6 +568,13 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     g.out_scale = gscale ? gscale + 1 : nullptr;  // f16: 1 / S
     gemm<T, A_PLAIN, EPI_UNPATCH>(m, g, st);
     CHECK_LAUNCH();
+    if (gscale) {  // f16: non-finite prompt gradient -> overflow flag + more headroom next time (rowops.hpp)
+      const long n4 = (long)B * 3 * (H / 2) * W / 4;
+      hipLaunchKernelGGL(grad_finite_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st,
+                         (const float*)gprompt, n4, (int*)(gscale + 16));
+      hipLaunchKernelGGL(grad_state_kernel, dim3(1), dim3(1), 0, st, (int*)(gscale + 16));
+      CHECK_LAUNCH();
+    }
   }
   return 0;
 }
@@ -726,6 +734,42 @@ int bsg_loss_fwd_bwd(void* stream, int batch, int h, int w, const float* pred, c
   return 0;
 }
 
+int bsg_loss_fwd_bwd_ids(void* stream, int batch, int h, int w, int K, const float* pred, const uint8_t* class_ids,
+                         const float* palette_norm, float beta, int variant, float* loss_out, float* grad_pred, void* scratch,
+                         size_t scratch_bytes) {
+  if (!pred || !class_ids || !palette_norm || !loss_out || !scratch) return fail("bsg_loss_fwd_bwd_ids: null argument");
+  if (variant != 0 && variant != 1) return fail("loss variant must be 0 (reference) or 1 (per_sample)");
+  if (K <= 0 || K > 256) return fail("bsg_loss_fwd_bwd_ids: K must be in 1..256");
+  if (scratch_bytes < bsg_loss_scratch_bytes(h, w)) return fail("loss scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long hw = (long)h * w;
+  unsigned long long* total = (unsigned long long*)scratch;
+  float* partial = (float*)((char*)scratch + 256);
+  float* counts = partial + kLossBlocks;
+  if (hipMemsetAsync(total, 0, 8, st) != hipSuccess) return fail("memset failed");
+  // yesdata = (class id != 0) (src/model.py:255 `mask != 0`): the id plane itself serves as the u8 truth plane
+  hipLaunchKernelGGL(loss_prep_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, st, class_ids, counts, total, batch, hw);
+  hipLaunchKernelGGL(loss_fwd_bwd_kernel, dim3(kLossBlocks), dim3(256), 0, st, pred, (const float*)nullptr, class_ids,
+                     (const float*)counts, (const unsigned long long*)total, grad_pred, partial, batch, h, w, beta, variant,
+                     class_ids, palette_norm, K);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, kLossBlocks,
+                     (const unsigned long long*)total, loss_out);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+int bsg_mask_rgb_norm(void* stream, int batch, int h, int w, int K, const uint8_t* class_ids, const uint8_t* palette,
+                      const float mean[3], const float std[3], float* out) {
+  if (!class_ids || !palette || !mean || !std || !out) return fail("bsg_mask_rgb_norm: null argument");
+  if (K <= 0 || K > 256) return fail("bsg_mask_rgb_norm: K must be in 1..256");
+  if (batch <= 0 || h <= 0 || w <= 0) return fail("bsg_mask_rgb_norm: bad geometry");
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(mask_rgb_norm_kernel, dim3((unsigned)std::min<long>((hw / 4 + 255) / 256 + 1, 1024), batch), dim3(256), 0,
+                     (hipStream_t)stream, class_ids, palette, out, hw, K, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+  CHECK_LAUNCH();
+  return 0;
+}
+
 int bsg_decode_argmin(void* stream, int batch, int h, int w, int K, const float* pred, const float* palette_norm,
                       int64_t* out_i64, uint8_t* out_u8) {
   if (!pred || !palette_norm || (!out_i64 && !out_u8)) return fail("bsg_decode_argmin: null argument");
@@ -773,6 +817,7 @@ int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, co
 
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias, void* out) {
   if (!A || !W || !out) return fail("bsg_op_gemm: null argument");
+  if (dtype != BSG_DTYPE_F32 && dtype != BSG_DTYPE_BF16 && dtype != BSG_DTYPE_F16) return fail("bsg_op_gemm: dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   if (K % (dtype == BSG_DTYPE_F32 ? 32 : 64) || N % 4) return fail("bsg_op_gemm: K must be a multiple of the 128-byte K tile, N of 4");
   bsg_model dummy{};
   GemmArgs g{};
@@ -784,6 +829,7 @@ int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, con
   if (nostore) { gemm<bf16_t, A_PLAIN, EPI_NONE>(&dummy, g, st); CHECK_LAUNCH(); return 0; }
 #endif
   if (dtype == BSG_DTYPE_F32) { if (bias) gemm<float, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<float, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
+  else if (dtype == BSG_DTYPE_F16) { if (bias) gemm<f16_t, A_PLAIN, EPI_BIAS>(&dummy, g, st); else gemm<f16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
 #ifdef BSG_DIAG_STAMPS  // the diagnostic build times the GELU epilogue through the bias entry
   else { if (bias) gemm<bf16_t, A_PLAIN, EPI_BIAS_GELU>(&dummy, g, st); else gemm<bf16_t, A_PLAIN, EPI_PLAIN>(&dummy, g, st); }
 #else
@@ -810,10 +856,11 @@ size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp) {
   return (size_t)S * nh * npad * 4 * ((size_t)hp + hp + 32 + 1) + 1024;
 }
 
-int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
-                     const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
-                     size_t scratch_bytes) {
-  typedef bf16_t T;
+}  // extern "C"
+template <typename T>
+static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
+                             const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
+                             size_t scratch_bytes) {
   if (!qkv || !rel_cat || !out || !lse2 || !scratch) return fail("bsg_op_attention: null argument");
   if ((which & 6) && (!rel_catT || !dout || !dqkv)) return fail("bsg_op_attention: backward needs rel_catT, dout, dqkv");
   if (hp % 2 || hp > 64 || wp > 32 || wp % 4) return fail("bsg_op_attention: bad token grid %d x %d", hp, wp);
@@ -866,6 +913,15 @@ int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, con
     CHECK_LAUNCH();
   }
   return 0;
+}
+
+extern "C" {
+int bsg_op_attention(void* stream, int dtype, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
+                     const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
+                     size_t scratch_bytes) {
+  if (dtype == BSG_DTYPE_BF16) return op_attention_impl<bf16_t>(stream, which, S, nh, hp, wp, qkv, rel_cat, rel_catT, dout, out, lse2, dqkv, scratch, scratch_bytes);
+  if (dtype == BSG_DTYPE_F16) return op_attention_impl<f16_t>(stream, which, S, nh, hp, wp, qkv, rel_cat, rel_catT, dout, out, lse2, dqkv, scratch, scratch_bytes);
+  return fail("bsg_op_attention: dtype must be 1 (bf16) or 2 (f16)");
 }
 
 int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* bands, const uint8_t* nodata, uint8_t* out_rgb,

@@ -47,7 +47,7 @@ def tif_image(bands: np.ndarray, nodata: np.ndarray | None = None) -> np.ndarray
 
 
 def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, generator: torch.Generator | None = None,
-                            with_color: bool = False):
+                            with_color: bool = False, erase_mask: bool = False):
     """Random parameters of the train-time augmentation chain (`src/data.py:195-224`), drawn on the host from an explicit
     generator (kornia draws them internally; kornia is not installable here, so the DISTRIBUTIONS follow kornia's
     documented parameter generators and the draw order is this function's own: "parity unpinned"):
@@ -57,7 +57,11 @@ def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, 
       U(-hue, hue) (turns), ONE random order of the four operations per batch;  RandomSharpness ~ Bernoulli(sharpness_p)
       with factor ~ U(0, sharpness).
     Returns (params i32 (B,5) = [flags, ex0, ey0, ew, eh], noise f32 (B,3,h,w) or None) and, with_color, a third item
-    color f32 (B,6) = [brightness, contrast, saturation, hue, sharpness factor, order code] (flags bits 3 / 4 set)."""
+    color f32 (B,6) = [brightness, contrast, saturation, hue, sharpness factor, order code] (flags bits 3 / 4 set).
+    `erase_mask` (flags bit 5): the erased box also becomes class 0 (nodata) in the MASK, which drops it from the loss
+    (`mask != 0`, `src/model.py:255`) -- what recent kornia versions do when `AugmentationSequential(data_keys=None)` routes
+    the mask through `RandomErasing` (`src/data.py:195-214`); off by default: which of the two the reference's unpinned
+    `kornia` did cannot be checked offline ("parity unpinned"), so both are built."""
     import math
 
     g = generator
@@ -89,111 +93,11 @@ def sample_train_aug_params(batch: int, h: int, w: int, config: BeachSegConfig, 
                              (u(batch) * 2 - 1) * config.hue, u(batch) * config.sharpness, torch.full((batch,), code)],
                             dim=1).float().contiguous()
         flags |= (sharp_on.int() << 3) | 16
+    if erase_mask:
+        flags |= erase.int() << 5
     params = torch.stack([flags, torch.where(erase, ex, zero), torch.where(erase, ey, zero), torch.where(erase, ew, zero),
                           torch.where(erase, eh, zero)], dim=1).to(torch.int32).contiguous()
     return (params, noise, color) if with_color else (params, noise)
-
-
-def _rgb_to_hsv(x: torch.Tensor) -> torch.Tensor:
-    """kornia.color.rgb_to_hsv on one (3,H,W) image: h in [0, 2 pi), s, v."""
-    import math
-
-    mx, imax = x.max(0)
-    mn = x.min(0)[0]
-    dc = mx - mn
-    s = dc / (mx + 1e-8)
-    dc = torch.where(dc == 0, torch.ones_like(dc), dc)
-    rc, gc, bc = (mx[None] - x).unbind(0)
-    hs = torch.stack([bc - gc, (rc - bc) + 2.0 * dc, (gc - rc) + 4.0 * dc]) / dc[None]
-    h = torch.gather(hs, 0, imax[None])[0]
-    h = (h / 6.0) % 1.0
-    return torch.stack([2.0 * math.pi * h, s, mx])
-
-
-def _hsv_to_rgb(x: torch.Tensor) -> torch.Tensor:
-    import math
-
-    h, s, v = x[0] / (2 * math.pi), x[1], x[2]
-    hi = torch.floor(h * 6) % 6
-    f = ((h * 6) % 6) - hi
-    p, q, t = v * (1.0 - s), v * (1.0 - f * s), v * (1.0 - (1.0 - f) * s)
-    hi = hi.long()
-    idx = torch.stack([hi, hi + 6, hi + 12])
-    table = torch.stack((v, q, p, p, t, v, t, v, v, q, p, p, p, p, t, v, v, q))
-    return torch.gather(table, 0, idx)
-
-
-def _color_jiggle(x: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
-    """kornia.augmentation.ColorJiggle.apply_transform on one image with explicit factors c = [brightness, contrast,
-    saturation, hue, -, order code] (kornia.enhance.adjust_brightness(f - 1) / adjust_contrast / adjust_saturation /
-    adjust_hue(2 pi f), applied in the coded order)."""
-    import math
-
-    order = int(c[5])
-    for k in range(4):
-        op = (order >> (2 * k)) & 3
-        if op == 0:
-            x = (x + (float(c[0]) - 1.0)).clamp(0, 1)
-        elif op == 1:
-            x = (x * float(c[1])).clamp(0, 1)
-        else:
-            hsv = _rgb_to_hsv(x)
-            if op == 2:
-                hsv = torch.stack([hsv[0], (hsv[1] * float(c[2])).clamp(0, 1), hsv[2]])
-            else:
-                hsv = torch.stack([torch.fmod(hsv[0] + float(c[3]) * 2 * math.pi, 2 * math.pi), hsv[1], hsv[2]])
-            x = _hsv_to_rgb(hsv)
-    return x
-
-
-def _sharpness(x: torch.Tensor, factor: float) -> torch.Tensor:
-    """kornia.enhance.sharpness on one (3,H,W) image: blend of the image with its clamped 3x3 [[1,1,1],[1,5,1],[1,1,1]]/13
-    blur (interior only), `_blend_one` rules for the clamp."""
-    import torch.nn.functional as F
-
-    k = (torch.tensor([[1.0, 1.0, 1.0], [1.0, 5.0, 1.0], [1.0, 1.0, 1.0]], dtype=x.dtype, device=x.device) / 13).view(1, 1, 3, 3)
-    d = F.conv2d(x[None], k.repeat(3, 1, 1, 1), groups=3)[0].clamp(0.0, 1.0)
-    inner = F.pad(torch.ones_like(d), [1, 1, 1, 1])
-    result = torch.where(inner == 1, F.pad(d, [1, 1, 1, 1]), x)
-    if factor == 0.0:
-        return result
-    if factor == 1.0:
-        return x
-    res = result + (x - result) * factor
-    return res if 0.0 < factor < 1.0 else res.clamp(0, 1)
-
-
-def train_aug_reference(img: torch.Tensor, mask: torch.Tensor | None, params: torch.Tensor, noise: torch.Tensor | None,
-                        mean=ml_util.IMAGE_MEAN, std=ml_util.IMAGE_STD, color: torch.Tensor | None = None):
-    """Plain-torch statement of what `ops.train_aug` computes (any device, autograd through torch): the test oracle of the
-    HIP kernels and the documentation of their semantics."""
-    out, mout = [], []
-    for b in range(img.shape[0]):
-        fl, ex, ey, ew, eh = (int(v) for v in params[b])
-        x = img[b]
-        m = mask[b] if mask is not None else None
-        if fl & 1:
-            x = x.flip(-2)
-            m = m.flip(-2) if m is not None else None
-        if fl & 2:
-            x = x.flip(-1)
-            m = m.flip(-1) if m is not None else None
-        if color is not None and fl & 16:
-            x = _color_jiggle(x, color[b])
-        if color is not None and fl & 8:
-            x = _sharpness(x, float(color[b, 4]))
-        if ew > 0 and eh > 0:
-            keep = torch.ones_like(x[0])
-            keep[ey:ey + eh, ex:ex + ew] = 0
-            x = x * keep
-        if fl & 4 and noise is not None:
-            x = x + noise[b].to(x.device)
-        out.append(x)
-        mout.append(m)
-    out = torch.stack(out)
-    mean_t = torch.tensor(mean, dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
-    std_t = torch.tensor(std, dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
-    return (out - mean_t) / std_t, (torch.stack(mout) if mask is not None else None)
 
 
 def pil_bicubic_tables(in_size: int, out_size: int) -> tuple[np.ndarray, np.ndarray]:
@@ -311,6 +215,7 @@ class BeachSegDataModule:
         self.mean, self.std = ml_util.IMAGE_MEAN, ml_util.IMAGE_STD
         self.normalize, self.denormalize = ml_util.normalize, ml_util.denormalize
         self.aug_generator = torch.Generator().manual_seed(config.seed + 2)
+        self.erase_mask = False  # True: RandomErasing also zeroes its box in the mask (see sample_train_aug_params)
         self.scene = scene or synthetic_dove_scene()
         size = next(iter(self.scene[0].values()))[0].shape[0]
         cs = config.crop_size
@@ -324,13 +229,15 @@ class BeachSegDataModule:
     def train_aug(self, batch: dict) -> dict:
         """`src/data.py:195-224` on the batch dict: flips (image and mask together), ColorJiggle, RandomSharpness,
         RandomErasing, Gaussian noise, Normalize, on device with backward to `batch["image"]` (`ops.train_aug`).  The two
-        colour operations follow kornia's published formulas ("parity unpinned": kornia is not installable here).  Random
-        parameters come from `self.aug_generator`."""
+        colour operations follow kornia's published formulas ("parity unpinned": kornia is not installable here), and so does
+        the mask side of RandomErasing: by default the mask only follows the flips; `self.erase_mask = True` also sets the
+        erased box to class 0 in the mask.  Random parameters come from `self.aug_generator`."""
         from . import ops
 
         img = batch["image"]
         B, _, h, w = img.shape
-        params, noise, color = sample_train_aug_params(B, h, w, self.config, self.aug_generator, with_color=True)
+        params, noise, color = sample_train_aug_params(B, h, w, self.config, self.aug_generator, with_color=True,
+                                                       erase_mask=self.erase_mask)
         mask = batch.get("mask")
         out, mo = ops.train_aug(img, mask, params.to(img.device), noise.to(img.device) if noise is not None else None,
                                 self.mean, self.std, color=color.to(img.device))

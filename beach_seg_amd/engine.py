@@ -9,7 +9,7 @@ which is `training_step` (`src/model.py:233-269`) + Lightning's `loss.backward()
 the current stream with no host synchronisation.
 
 The path shards by sample: each rank takes its own B tiles (weak scaling).  The only exchange is ONE sum
-all-reduce per step of the flat prompt-gradient buffer plus its P "touched" flags (P x 602,112 fp32; 154 MB at
+all-reduce per step of the flat prompt-gradient buffer plus its P "touched" flags and one overflow flag (P x 602,112 fp32; 154 MB at
 P = 64), the DDP-equivalent of the gradients the reference would reduce; gradients are averaged over ranks as
 DDP does.
 """
@@ -91,24 +91,45 @@ class PromptTrainEngine:
         if self.world > 1:  # replicas must start from the same parameters, as DDP guarantees at construction
             broadcast_from_rank0(self.params, process_group)
         n = self.params[0].numel()
-        self._flat = torch.zeros(P * n + P, dtype=torch.float32, device=dev)
+        # ... and ONE more float: the f16 overflow flag of this rank's backward (any rank overflowing skips the step on all)
+        self._flat = torch.zeros(P * n + P + 1, dtype=torch.float32, device=dev)
         self.grads = self._flat[: P * n].view_as(self.params)
-        self._touched_f = self._flat[P * n:]
+        self._touched_f = self._flat[P * n: P * n + P]
+        self._overflow_f = self._flat[P * n + P:]
+        self.skipped_steps = torch.zeros((), dtype=torch.int64, device=dev)  # steps dropped by the overflow guard
 
     def step(self, pixel_values: torch.Tensor, label_color: torch.Tensor, yesdata: torch.Tensor,
              prompt_idx: torch.Tensor, prompt_mask_color: torch.Tensor) -> torch.Tensor:
         """One optimiser step on this rank's batch; returns this rank's loss (device scalar, no sync)."""
+        return self._step(pixel_values, prompt_idx, prompt_mask_color,
+                          lambda pred: ops.loss_fwd_bwd(pred, label_color, yesdata, self.loss_beta, self.loss_variant, True))
+
+    def step_ids(self, pixel_values: torch.Tensor, label_ids: torch.Tensor, palette: torch.Tensor,
+                 palette_norm: torch.Tensor, prompt_idx: torch.Tensor, prompt_mask_ids: torch.Tensor) -> torch.Tensor:
+        """The same step from what `training_step` actually holds (`src/model.py:233-255`): label class ids u8 (B,[1,]h,w),
+        the batch palette u8 (B,K,3) + its normalised copy f32 (B,K,3), the class ids of the chosen prompts' masks.  The
+        prompt mask is colourised + normalised by one kernel (`bsg_mask_rgb_norm`); the label image is never formed -- the
+        loss kernel reads class id and palette (`bsg_loss_fwd_bwd_ids`), yesdata = (id != 0)."""
+        prompt_mask_color = ops.mask_rgb_norm(palette, prompt_mask_ids)
+        return self._step(pixel_values, prompt_idx, prompt_mask_color,
+                          lambda pred: ops.loss_fwd_bwd_ids(pred, label_ids, palette_norm, self.loss_beta, self.loss_variant, True))
+
+    def _step(self, pixel_values, prompt_idx, prompt_mask_color, loss_and_grad) -> torch.Tensor:
         m = self.model
         B = pixel_values.shape[0]
         self._flat.zero_()
         prompts = ops.prompt_gather(self.params, prompt_idx)  # stack + Normalize
         pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True)
-        loss, gpred = ops.loss_fwd_bwd(pred, label_color, yesdata, self.loss_beta, self.loss_variant, True)
+        loss, gpred = loss_and_grad(pred)
         gpix = m._run_backward(gpred, B, first_row=pred.shape[2] // 2)  # the loss gradient is zero on the prompt half
         ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
         self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
+        if m.dtype == torch.float16:  # device-side overflow guard of the half-precision dgrad chain (no host sync)
+            self._overflow_f.copy_(m.grad_overflow_state(B)[:1])
         reduce_prompt_grads(self._flat, self.pg)  # RCCL over xGMI when world > 1
-        touched = (self._touched_f > 0).to(torch.uint8)
+        ok = self._overflow_f == 0  # an overflow on ANY rank drops the step on every rank: replicas stay identical
+        self.skipped_steps += (~ok).sum()
+        touched = ((self._touched_f > 0) & ok).to(torch.uint8)
         self.steps += touched.long()
         ops.adamw_step(self.params.view(self.params.shape[0], -1), self.grads.view(self.params.shape[0], -1),
                        self.exp_avg.view(self.params.shape[0], -1), self.exp_avg_sq.view(self.params.shape[0], -1),

@@ -68,13 +68,12 @@ def generate_random_rgb_palette(num_labels: int, batch_size: int, device, genera
 
 
 def torch_apply_mask_rgb(palette: torch.Tensor, input: torch.Tensor) -> torch.Tensor:
-    """`src/util/ml_util.py:114-132`: class ids (B,1,H,W)/(B,H,W) -> f32 (B,3,H,W) in [0,1]."""
-    if input.ndim == 3:
-        input = input.unsqueeze(1)
-    mask = input.squeeze(1).to(torch.long)
-    B = mask.shape[0]
-    rgb = palette[torch.arange(B, device=mask.device)[:, None, None], mask]
-    return rgb.permute(0, 3, 1, 2).to(dtype=torch.float32) / 255.0
+    """`src/util/ml_util.py:114-132`: class ids (B,1,H,W)/(B,H,W) -> f32 (B,3,H,W) in [0,1], on the HIP kernel
+    (`bsg_mask_rgb_norm` with mean 0 / std 1: palette / 255 exactly).  The hot path uses the fused form
+    `ops.mask_rgb_norm` (LUT gather + Normalize in one pass) or skips the image altogether (`ops.seggpt_loss_ids`)."""
+    from . import ops
+
+    return ops.mask_rgb_norm(palette, input, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0))
 
 
 _CONST_CACHE: dict = {}

@@ -29,6 +29,11 @@ class SegGptLoss(torch.nn.Module):
     def forward(self, pred_masks, labels, yesdata):
         return ops.seggpt_loss(pred_masks, labels, yesdata, self.beta, self.variant)
 
+    def forward_ids(self, pred_masks, class_ids, palette_norm):
+        """`forward(pred, normalize(torch_apply_mask_rgb(palette, class_ids)), class_ids != 0)` (`src/model.py:238-239,
+        255`) with the colourisation folded into the loss kernel."""
+        return ops.seggpt_loss_ids(pred_masks, class_ids, palette_norm, self.beta, self.variant)
+
 
 class MulticlassF1:
     """`torchmetrics.MulticlassF1Score(num_classes, ignore_index=0)` (macro average; `src/model.py:85-93`).  State = the
@@ -135,6 +140,13 @@ class PromptModel(torch.nn.Module):
         params = [torch.nn.Parameter(torch.as_tensor(p["image"], dtype=torch.float32).to(dev).clone()) for p in prompt_imgs]
         self.prompt_params_list = torch.nn.ParameterList(params)
         self.prompt_batch["image"] = params
+        self.invalidate_prompt_cache()
+
+    def invalidate_prompt_cache(self) -> None:
+        """Drop the no-grad path's stacked copy of the prompt Parameters.  `prepare_prompt` also detects in-place updates
+        through the Parameters' version counters; call this after an edit those cannot see (`p.data = ...`, an external
+        engine writing the storage through a raw pointer)."""
+        self._prompt_stack = None
 
     # ---- src/model.py:215-231
     def _palette_host(self, batch_size: int, train: bool) -> torch.Tensor:
@@ -143,27 +155,42 @@ class PromptModel(torch.nn.Module):
         p = torch.tensor(ml_util.build_palette(self.num_classes - 1), dtype=torch.uint8)
         return torch.stack([p for _ in range(batch_size)])
 
-    def _palette_norm(self, pal: torch.Tensor) -> torch.Tensor:
-        mean, std = ml_util.mean_std(self.device)
-        return (pal.to(torch.float32) / 255 - mean.view(3)) / std.view(3)
+    @staticmethod
+    def _palette_norm(pal: torch.Tensor) -> torch.Tensor:
+        """Normalised palette on the HOST in float32, `(c / 255 - mean) / std` with true divisions -- the bits the
+        reference's CPU run holds (`src/model.py:221-229`).  (On the GPU torch evaluates `x / 255` as `x * (1 / 255)`, one
+        ulp off on some entries; the arg-min decode and the id-based loss compare against these values.)"""
+        mean, std = torch.tensor(ml_util.IMAGE_MEAN), torch.tensor(ml_util.IMAGE_STD)
+        return (pal.cpu().to(torch.float32) / 255 - mean) / std
 
     def create_palette(self, batch_size: int, train: bool) -> tuple[torch.Tensor, torch.Tensor]:
-        pal = self._palette_host(batch_size, train).to(self.device)
-        return pal, self._palette_norm(pal)
+        pal = self._palette_host(batch_size, train)
+        return pal.to(self.device), self._palette_norm(pal).to(self.device)
 
-    def create_palettes(self, batch_sizes: list[int], train: bool) -> list[tuple[torch.Tensor, torch.Tensor]]:
-        """The palettes of a whole predict loop, drawn on the host in batch order (the same generator sequence as one
-        `create_palette` per batch) and uploaded ONCE: a per-batch upload is a blocking copy that keeps the host from
-        queueing batch i + 1 while batch i runs."""
+    def draw_palette_rows(self, batch_sizes: list[int], train: bool) -> torch.Tensor:
+        """u8 (sum(batch_sizes), K, 3) on the HOST: one `create_palette` draw per batch, in batch order (the generator
+        sequence of the reference's per-batch `create_palette(B, train=True)`, `src/model.py:134`)."""
+        if not batch_sizes:
+            return torch.zeros(0, self.num_classes, 3, dtype=torch.uint8)
+        return torch.cat([self._palette_host(n, train) for n in batch_sizes])
+
+    def split_palette_rows(self, rows: torch.Tensor, batch_sizes: list[int]) -> list[tuple[torch.Tensor, torch.Tensor]]:
+        """Host palette rows -> per-batch (palette u8, normalised palette f32) device views, uploaded ONCE."""
         if not batch_sizes:
             return []
-        pal = torch.cat([self._palette_host(n, train) for n in batch_sizes]).to(self.device)
-        norm = self._palette_norm(pal)
+        norm = self._palette_norm(rows).to(self.device)
+        pal = rows.to(self.device)
         out, s = [], 0
         for n in batch_sizes:
             out.append((pal[s:s + n], norm[s:s + n]))
             s += n
         return out
+
+    def create_palettes(self, batch_sizes: list[int], train: bool) -> list[tuple[torch.Tensor, torch.Tensor]]:
+        """The palettes of a whole predict loop, drawn on the host in batch order (the same generator sequence as one
+        `create_palette` per batch) and uploaded ONCE: a per-batch upload is a blocking copy that keeps the host from
+        queueing batch i + 1 while batch i runs."""
+        return self.split_palette_rows(self.draw_palette_rows(batch_sizes, train), batch_sizes)
 
     # ---- src/model.py:177-213
     def prepare_prompt(self, batch_idxes, batch_palette: torch.Tensor, train: bool):
@@ -177,8 +204,12 @@ class PromptModel(torch.nn.Module):
         if torch.is_grad_enabled():
             image = torch.stack([self.prompt_batch["image"][i] for i in idx], dim=0)  # autograd-tracked stack
         else:  # inference (predict loop): one gather from a cached stack instead of B Parameter reads
-            if self._prompt_stack is None or self._prompt_stack[0] is not self.prompt_batch["image"]:
-                self._prompt_stack = (self.prompt_batch["image"], torch.stack([p.detach() for p in self.prompt_batch["image"]]))
+            # keyed on the list AND on every Parameter's version counter: optimizer.step() / .copy_() / .data edits bump
+            # `_version` in place without changing the list's identity, and validation after training must see them
+            params = self.prompt_batch["image"]
+            key = (id(params), tuple(id(p) for p in params), tuple(p._version for p in params))
+            if self._prompt_stack is None or self._prompt_stack[0] != key:
+                self._prompt_stack = (key, torch.stack([p.detach() for p in params]))
             image = self._prompt_stack[1].index_select(0, sel)
         mask = self.prompt_batch["mask"][sel]
         aug = self.train_aug if train else self.aug
@@ -190,7 +221,7 @@ class PromptModel(torch.nn.Module):
         crop_idx = (self.prompt_batch["crop_idx"].to(self.device)[sel] if on_device
                     else self.prompt_batch["crop_idx"][torch.tensor(idx)])
         prompt_batch = {"image": image_n, "mask": mask, "crop_idx": crop_idx}
-        prompt_color = self.normalize(ml_util.torch_apply_mask_rgb(batch_palette, mask))
+        prompt_color = ops.mask_rgb_norm(batch_palette, mask)  # normalize(torch_apply_mask_rgb(...)), src/model.py:211-212
         return prompt_batch, prompt_color
 
     # ---- src/model.py:155-175
@@ -213,12 +244,14 @@ class PromptModel(torch.nn.Module):
         B = batch["mask"].shape[0]
         mask = batch["mask"].to(self.device)
         pal, pal_norm = self.create_palette(B, train=True)
-        color_mask_norm = self.normalize(ml_util.torch_apply_mask_rgb(pal, mask))
         prompt_batch, prompt_masks = self.prepare_prompt(prompt_idx, pal, train=train)
-        out = self.model(pixel_values=batch["image"].to(self.device), labels=color_mask_norm,
+        # The reference colourises the label (`src/model.py:238-239`) and hands it to the network as `labels=`, where the
+        # default bool_masked_pos drops it (HF:706-715); its only consumer is the loss, which here reads the class ids and
+        # the normalised palette directly (`bsg_loss_fwd_bwd_ids`): no f32 label image exists on this path.
+        out = self.model(pixel_values=batch["image"].to(self.device), labels=None,
                          prompt_pixel_values=prompt_batch["image"], prompt_masks=prompt_masks, embedding_type="instance")
         pred_masks = self.process_pred_masks(out.pred_masks, pal_norm)
-        loss = self.loss_fn(out.pred_masks, color_mask_norm, mask != 0)
+        loss = self.loss_fn.forward_ids(out.pred_masks, mask, pal_norm)
         metrics.update(pred_masks, mask.squeeze(1))
         return loss
 
@@ -248,7 +281,11 @@ class PromptModel(torch.nn.Module):
         optimizer.zero_grad(set_to_none=True)
         loss = self.training_step(batch)
         loss.backward()
+        if getattr(self.model, "last_backward_overflowed", lambda: False)():  # f16 dgrad chain overflowed: skip, like GradScaler
+            optimizer.zero_grad(set_to_none=True)
+            return loss.detach()
         optimizer.step()
+        self.invalidate_prompt_cache()
         return loss.detach()
 
     def on_epoch_end(self, optimizer: torch.optim.Optimizer) -> None:

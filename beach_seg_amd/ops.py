@@ -67,6 +67,67 @@ def seggpt_loss(pred, labels, yesdata, beta: float, variant: str = "reference") 
     return _LossFn.apply(pred, labels, yesdata, beta, variant)
 
 
+def loss_fwd_bwd_ids(pred, class_ids, palette_norm, beta: float, variant: str, want_grad: bool):
+    """`loss_fwd_bwd` with the label image left un-materialised (`bsg_loss_fwd_bwd_ids`): class_ids u8 (B,h,w) /
+    (B,1,h,w), palette_norm f32 (B,K,3); label pixel = palette_norm[b][id], yesdata = (id != 0)."""
+    lib = N.load()
+    B, _, H2, W = pred.shape
+    h, K = H2 // 2, palette_norm.shape[1]
+    pred_c = pred.detach().float().contiguous()
+    ids = class_ids.reshape(B, h, W).to(torch.uint8).contiguous()
+    pal = palette_norm.detach().float().contiguous()
+    if tuple(pal.shape) != (B, K, 3):
+        raise ValueError(f"palette_norm must be (B, K, 3), got {tuple(pal.shape)}")
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred_c) if want_grad else None
+    scratch = torch.empty(lib.bsg_loss_scratch_bytes(h, W), dtype=torch.uint8, device=pred.device)
+    with torch.cuda.device(pred.device):
+        N.check(lib.bsg_loss_fwd_bwd_ids(_stream(), B, h, W, K, _ptr(pred_c), _ptr(ids), _ptr(pal), float(beta),
+                                         VARIANTS[variant], _ptr(loss), _ptr(grad), _ptr(scratch), scratch.numel()))
+    return loss[0], grad
+
+
+class _LossIdsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, class_ids, palette_norm, beta, variant):
+        loss, ctx.grad = loss_fwd_bwd_ids(pred, class_ids, palette_norm, beta, variant, pred.requires_grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None, None, None
+
+
+def seggpt_loss_ids(pred, class_ids, palette_norm, beta: float, variant: str = "reference") -> torch.Tensor:
+    """`SegGptLoss.forward(pred, Normalize(torch_apply_mask_rgb(palette, mask)), mask != 0)` (`src/model.py:238-239, 255`)
+    without materialising the f32 label image: the kernel reads the class id and looks the colour up."""
+    _need_gpu(pred, class_ids, palette_norm)
+    if variant not in VARIANTS:
+        raise ValueError(f"variant must be one of {list(VARIANTS)}")
+    return _LossIdsFn.apply(pred, class_ids, palette_norm, beta, variant)
+
+
+def mask_rgb_norm(palette: torch.Tensor, class_ids: torch.Tensor, mean=IMAGE_MEAN, std=IMAGE_STD) -> torch.Tensor:
+    """`normalize(torch_apply_mask_rgb(palette, input))` (`src/util/ml_util.py:114-132` + `src/data.py:345`; call sites
+    `src/model.py:211-212, 238-239`) in ONE HIP kernel: palette u8 (B,K,3), class ids u8 (B,1,H,W) / (B,H,W) -> f32
+    (B,3,H,W), bit-exact against the reference's float32 CPU arithmetic.  mean=(0,0,0), std=(1,1,1): the un-normalised
+    [0,1] image of `torch_apply_mask_rgb` alone."""
+    _need_gpu(palette, class_ids)
+    if palette.dtype != torch.uint8 or palette.dim() != 3 or palette.shape[2] != 3:
+        raise ValueError("palette must be uint8 (B, K, 3)")
+    ids = class_ids[:, 0] if class_ids.dim() == 4 else class_ids
+    if ids.dim() != 3 or ids.shape[0] != palette.shape[0]:
+        raise ValueError(f"class ids must be (B,1,H,W) or (B,H,W) with B = {palette.shape[0]}, got {tuple(class_ids.shape)}")
+    lib = N.load()
+    B, h, w = ids.shape
+    ids = ids.to(torch.uint8).contiguous()
+    out = torch.empty((B, 3, h, w), dtype=torch.float32, device=ids.device)
+    with torch.cuda.device(ids.device):
+        N.check(lib.bsg_mask_rgb_norm(_stream(), B, h, w, palette.shape[1], _ptr(ids), _ptr(palette.contiguous()), _f3(mean),
+                                      _f3(std), _ptr(out)))
+    return out
+
+
 def decode_argmin(pred: torch.Tensor, palette_norm: torch.Tensor, out_dtype=torch.int64) -> torch.Tensor:
     """`process_pred_masks` (`src/model.py:155-175`) -> (B,H,W) int64 (reference dtype) or uint8."""
     _need_gpu(pred, palette_norm)
@@ -224,16 +285,19 @@ def post_process_semantic_segmentation(pred_masks: torch.Tensor, num_labels: int
     return res
 
 
+_DTYPE_CODE = {torch.float32: N.BSG_DTYPE_F32, torch.bfloat16: N.BSG_DTYPE_BF16, torch.float16: N.BSG_DTYPE_F16}
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16 or both f32."""
     _need_gpu(a, w, bias)
     lib = N.load()
-    if a.dtype != w.dtype or a.dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("a and w must both be float32 or both bfloat16")
+    if a.dtype != w.dtype or a.dtype not in _DTYPE_CODE:
+        raise ValueError("a and w must both be float32, both bfloat16 or both float16")
     M, K = a.shape
     out = torch.empty((M, w.shape[0]), dtype=a.dtype, device=a.device)
     with torch.cuda.device(a.device):
-        N.check(lib.bsg_op_gemm(_stream(), 0 if a.dtype == torch.float32 else 1, M, w.shape[0], K, _ptr(a.contiguous()),
+        N.check(lib.bsg_op_gemm(_stream(), _DTYPE_CODE[a.dtype], M, w.shape[0], K, _ptr(a.contiguous()),
                                 _ptr(w.contiguous()), _ptr(bias), _ptr(out)))
     return out
 
@@ -245,12 +309,14 @@ def attention_scratch(S: int, nh: int, hp: int, device) -> torch.Tensor:
 def attention(which: int, qkv: torch.Tensor, rel_cat: torch.Tensor, S: int, nh: int, hp: int, wp: int, out: torch.Tensor,
               lse2: torch.Tensor, scratch: torch.Tensor, rel_catT: torch.Tensor | None = None,
               dout: torch.Tensor | None = None, dqkv: torch.Tensor | None = None) -> None:
-    """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV.  bf16 tensors:
+    """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV.  bf16 or f16 tensors:
     qkv (S*N, 3*nh*64), rel_cat ([LH+LW], 64) / rel_catT, dout / out (S*N, nh*64), dqkv like qkv; lse2 f32 (S, nh, hp*32)."""
     _need_gpu(qkv, rel_cat, out, lse2, scratch)
     lib = N.load()
     with torch.cuda.device(qkv.device):
-        N.check(lib.bsg_op_attention(_stream(), which, S, nh, hp, wp, _ptr(qkv), _ptr(rel_cat), _ptr(rel_catT), _ptr(dout),
+        if qkv.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("the stand-alone attention entry takes bfloat16 or float16 tensors")
+        N.check(lib.bsg_op_attention(_stream(), _DTYPE_CODE[qkv.dtype], which, S, nh, hp, wp, _ptr(qkv), _ptr(rel_cat), _ptr(rel_catT), _ptr(dout),
                                      _ptr(out), _ptr(lse2), _ptr(dqkv), _ptr(scratch), scratch.numel()))
 
 

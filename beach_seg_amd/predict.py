@@ -20,8 +20,13 @@ class Accumulator:
     one (`__exit__`, `:90-91`).  "Finalise" here = arg-max over the votes (`:100`) handed to `on_finish(date, mosaic)`
     and kept in `finished`; the PNG / GeoTIFF export of `:93-112` is the caller's (out of scope)."""
 
-    def __init__(self, out_shape: tuple[int, int], classes: tuple[str, ...], device, on_finish=None):
+    def __init__(self, out_shape: tuple[int, int], classes: tuple[str, ...], device, on_finish=None, world: int = 1,
+                 process_group=None):
+        """`world` > 1 (sharded predict): every finalisation -- date change, `__exit__`, `save_current` -- first sums the
+        ranks' vote counters, so each rank finalises the FULL mosaic of that date; all ranks must then see the same date
+        sequence (a rank without windows for a date still calls `update` with zero crops, or `initialize_current`)."""
         self.out_shape, self.num_classes, self.classes, self.device = out_shape, len(classes), classes, device
+        self.world, self.process_group = world, process_group
         self.current_date = None
         self.current_pred_counter = None
         self.on_finish = on_finish
@@ -36,6 +41,8 @@ class Accumulator:
 
     def save_current(self) -> torch.Tensor:
         assert self.current_pred_counter is not None and self.current_date is not None
+        if self.world > 1 and not self._reduced:
+            self.reduce_votes(self.process_group)
         pred = ops.vote_argmax(self.current_pred_counter)
         self.finished.append((self.current_date, pred))
         if self.on_finish is not None:
@@ -44,6 +51,7 @@ class Accumulator:
 
     def initialize_current(self, date: str) -> None:
         self.current_date = date
+        self._reduced = False
         self.current_pred_counter = torch.zeros((*self.out_shape, self.num_classes), dtype=torch.uint8, device=self.device)
 
     def update(self, date: str, crops: torch.Tensor, masks: torch.Tensor, crop_size: int,
@@ -67,8 +75,11 @@ class Accumulator:
         vote counters once, before the arg-max.  uint8 addition wraps at 256 on every backend, exactly like the single
         process's `+= 1` (`src/predict.py:150-159`), so the reduced mosaic is bit-identical to the unsharded one."""
         reduce_vote_counters(self.current_pred_counter, process_group)
+        self._reduced = True
 
     def result(self) -> torch.Tensor:
+        if self.world > 1 and not self._reduced:
+            self.reduce_votes(self.process_group)
         return ops.vote_argmax(self.current_pred_counter)
 
 
@@ -129,11 +140,17 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
     Returns the u8 (H,W) class mosaic.  All-nodata crops are the caller's to skip (`src/predict.py:235`).
     `use_graph`: replay the network forward from one captured hipGraph (full batches only; the tail runs eagerly).
     `world` > 1: this rank takes windows rank, rank + world, ... (every rank is a replica of the network), the vote
-    counters are summed once at the end and every rank returns the full mosaic -- bit-identical to world = 1."""
-    acc = Accumulator(out_shape, model.conf.classes, model.device)
+    counters are summed once at the end and every rank returns the full mosaic.  The reference draws a RANDOM palette per
+    batch (`src/model.py:134`); here every rank draws the palettes of the UNSHARDED loop (same generator, same batch
+    sizes) and window i keeps row i of that sequence wherever it runs, so the sharded mosaic is bit-identical to the
+    world = 1 run of the same `model.palette_g` state (identical seeds on all ranks assumed, as `PromptModel` sets them)."""
+    acc = Accumulator(out_shape, model.conf.classes, model.device, world=world, process_group=process_group)
     disjoint = crops_are_disjoint(crops)  # decided once per mosaic: no host round trip per batch of windows
+    n_global = images.shape[0]
+    pal_rows = model.draw_palette_rows([min(batch_size, n_global - s) for s in range(0, n_global, batch_size)], train=True)
     if world > 1:
         images, crop_idx, crops = images[rank::world], crop_idx[rank::world], crops[rank::world]
+        pal_rows = pal_rows[rank::world]
     acc.initialize_current(date)  # a rank without windows still joins the reduction with an all-zero counter
     # everything the loop needs from the host goes up ONCE: a per-batch upload blocks the host until the stream has
     # drained, i.e. until the previous batch's forward is done, and the GPU then idles through the host's share of a batch
@@ -141,7 +158,7 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
     idx_dev = crop_idx.to(model.device)
     n_total = images.shape[0]
     sizes = [min(batch_size, n_total - s) for s in range(0, n_total, batch_size)]
-    palettes = model.create_palettes(sizes, train=True)  # the reference draws a random palette per batch (src/model.py:138)
+    palettes = model.split_palette_rows(pal_rows, sizes)  # uploaded once
     graphed = model.model.capture_forward(batch_size) if use_graph and n_total >= batch_size else None
     with torch.no_grad():
         for b, s in enumerate(range(0, n_total, batch_size)):
@@ -156,9 +173,7 @@ def predict_mosaic(model: PromptModel, images: torch.Tensor, crop_idx: torch.Ten
                                   embedding_type="instance").pred_masks
             pred = model.process_pred_masks(out, pal_norm)
             acc.update(date, crops_dev[sl] if disjoint else crops[sl], pred.to(torch.uint8), crop_size, disjoint=disjoint)
-    if world > 1:
-        acc.reduce_votes(process_group)
-    return acc.result()
+    return acc.result()  # world > 1: sums the ranks' counters first
 
 
 def grid_crops(height: int, width: int, crop_size: int, stride: int | None = None) -> torch.Tensor:

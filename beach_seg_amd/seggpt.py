@@ -172,6 +172,7 @@ class _SegGptFn(torch.autograd.Function):
         if ctx.lease is None:
             raise RuntimeError("backward through a forward that saved no activations")
         g = ctx.model._run_backward(grad_pred.contiguous().float(), ctx.batch, ws=ctx.lease.ws)
+        ctx.model._last_bwd = (ctx.batch, ctx.lease.ws)
         return None, None, g, None, None, None
 
 
@@ -215,6 +216,7 @@ class SegGptNative(torch.nn.Module):
         self._train_ws: dict[int, list[torch.Tensor]] = {}  # per batch size: saved-activation workspaces
         self._leased: set[int] = set()                      # data_ptrs held by live autograd nodes (_WsLease)
         self._last_ws: Optional[torch.Tensor] = None
+        self._last_bwd: Optional[tuple[int, torch.Tensor]] = None  # (batch, workspace) of the last autograd backward
 
     def __del__(self):
         try:
@@ -314,6 +316,22 @@ class SegGptNative(torch.nn.Module):
             N.check(self._lib.bsg_backward_rows(self._h, _stream(), B, _ptr(grad_pred), int(first_row), _ptr(g), _ptr(ws),
                                                 ws.numel()))
         return g
+
+    def grad_overflow_state(self, batch: int, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """int32 device view [overflow flag of the last backward, back-off exponent, clean backwards, overflows so far] of
+        the f16 overflow guard (`include/beach_seg_amd.h`, region "gscale"); all zero for the other dtypes.  `ws`: the
+        workspace of that backward (default: the engine's last one).  No synchronisation: act on it on the stream."""
+        ws = ws if ws is not None else (self._last_ws if self._last_ws is not None else self.workspace(batch, True))
+        off, nb = C.c_size_t(), C.c_size_t()
+        N.check(self._lib.bsg_workspace_region(self._h, batch, 1, b"gscale", -1, C.byref(off), C.byref(nb)))
+        return ws[off.value + 64: off.value + 80].view(torch.int32)
+
+    def last_backward_overflowed(self) -> bool:
+        """f16 only: did the last autograd backward produce a non-finite prompt gradient?  (Host synchronisation, like
+        `GradScaler.step`: the caller skips `optimizer.step()` when True.)"""
+        if self.dtype != torch.float16 or self._last_bwd is None:
+            return False
+        return bool(int(self.grad_overflow_state(*self._last_bwd)[0]))
 
     def capture_forward(self, batch: int, embedding_type: str = "instance") -> "GraphedForward":
         """Capture one inference forward (no autograd) of `batch` samples into a hipGraph.  The C ABI enqueues

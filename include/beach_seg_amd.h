@@ -93,6 +93,12 @@ int bsg_forward_ensemble(bsg_model* m, void* stream, int batch, const float* pix
  * (src/util/ml_util.py:9-10). */
 int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, float* grad_prompt_pixel_values,
                  void* workspace, size_t workspace_bytes);
+/* BSG_DTYPE_F16 overflow guard: the backward checks the prompt gradient it produced; workspace region "gscale"
+ * (bsg_workspace_region(m, batch, 1, "gscale", -1, ...)) holds, as int32 at byte offset 64: [0] 1 if the LAST backward on
+ * this workspace produced a non-finite gradient (the caller must then skip its optimiser step, as torch's GradScaler
+ * does), [1] the back-off exponent in force (raised by 2 per overflow: 4x more headroom for the next backward; lowered by
+ * 1 after 1000 clean backwards), [2] clean backwards since the last change, [3] overflows so far.  Device memory: read it
+ * on the stream (no host round trip is needed to act on it).  Always 0 for the other dtypes. */
 
 /* Same, for a grad_pred the caller guarantees to be zero on canvas rows < first_row (what bsg_loss_fwd_bwd produces
  * with first_row = H/2: the reference loss only covers the query half, src/model.py:53-57).  The decoder dgrad then
@@ -108,6 +114,21 @@ size_t bsg_loss_scratch_bytes(int h, int w);
 int bsg_loss_fwd_bwd(void* stream, int batch, int h, int w, const float* pred, const float* labels,
                      const uint8_t* yesdata, float beta, int variant, float* loss_out, float* grad_pred,
                      void* scratch, size_t scratch_bytes);
+
+/* The same loss with the label image left un-materialised: class_ids u8 (B,h,w) are the label classes
+ * (batch["mask"], src/model.py:236), palette_norm f32 (B,K,3) the normalised palette of create_palette
+ * (src/model.py:215-231); the label pixel is palette_norm[b][id][c] -- the bits Normalize(torch_apply_mask_rgb(palette,
+ * mask)) (src/model.py:238-239) would hold -- and yesdata = (id != 0) (src/model.py:255).  Same scratch. */
+int bsg_loss_fwd_bwd_ids(void* stream, int batch, int h, int w, int K, const float* pred, const uint8_t* class_ids,
+                         const float* palette_norm, float beta, int variant, float* loss_out, float* grad_pred,
+                         void* scratch, size_t scratch_bytes);
+
+/* torch_apply_mask_rgb + Normalize (src/util/ml_util.py:114-132, src/data.py:345; call sites src/model.py:211-212,
+ * 238-239): class_ids u8 (B,h,w), palette u8 (B,K,3) -> out f32 (B,3,h,w) = (palette[b][id][c] / 255 - mean[c]) / std[c],
+ * each step one correctly rounded float32 operation (bit-exact against the reference's CPU result).  mean = 0, std = 1
+ * gives torch_apply_mask_rgb alone.  Ids >= K read entry K-1 (torch would raise). */
+int bsg_mask_rgb_norm(void* stream, int batch, int h, int w, int K, const uint8_t* class_ids, const uint8_t* palette,
+                      const float mean[3], const float std[3], float* out);
 
 /* process_pred_masks (src/model.py:155-175): arg-min over K normalised palette colours on the bottom half.
  * pred f32 (B,3,2h,w), palette_norm f32 (B,K,3); either output may be NULL. */
@@ -166,7 +187,7 @@ int bsg_tif_image(void* stream, int C, int H, int W, int in_dtype, const void* b
 /* Train-time augmentation of src/data.py:195-224 with EXPLICIT random parameters (the reference draws them inside
  * kornia): per sample params[b] = {flags, ex0, ey0, ew, eh}, flags bit 0 = vertical flip, bit 1 = horizontal flip, bit 2 =
  * add `noise` (f32 (B,3,h,w), already scaled by gauss_std and shifted by gauss_mean), bit 3 = RandomSharpness applied,
- * bit 4 = ColorJiggle applied; the e* box is erased to 0 (ew = 0: none).  color (NULL: neither colour operation): f32
+ * bit 4 = ColorJiggle applied, bit 5 = the erased box is also set to class 0 in mask_out; the e* box is erased to 0 (ew = 0: none).  color (NULL: neither colour operation): f32
  * (B,6) = {brightness, contrast, saturation, hue factor (in turns, kornia's hue_factor), sharpness factor, order code}
  * with order code = i0 | i1<<2 | i2<<4 | i3<<6, operation i0 first (0 brightness, 1 contrast, 2 saturation, 3 hue).
  * Order: flips -> ColorJiggle -> RandomSharpness -> erase -> noise -> Normalize.  The two colour operations follow
@@ -188,17 +209,17 @@ int bsg_confusion_update(void* stream, long n, int K, int ignore_index, const in
                          const uint8_t* target, uint64_t* confmat);
 
 /* The NT GEMM kernel on its own (unit tests and micro-benchmarks): out[M][N] = A[M][K] W[N][K]^T (+ bias[N]),
- * A / W / out in the dtype given (0 f32, 1 bf16), bias f32 or NULL. */
+ * A / W / out in the dtype given (BSG_DTYPE_*), bias f32 or NULL. */
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,
                 void* out);
 
-/* The fused attention kernels on their own (unit tests and micro-benchmarks), bf16: qkv T[S*N][3*nh*64] (q | k | v column
+/* The fused attention kernels on their own (unit tests and micro-benchmarks), T = bf16 or f16 (dtype 1 / 2): qkv T[S*N][3*nh*64] (q | k | v column
  * blocks, head h at columns h*64), N = hp*wp tokens per stream; rel_cat / rel_catT as in the weight table (slots 18 / 19);
  * `which` bit 0: forward -> out T[S*N][nh*64], lse2 f32[S][nh][hp*32]; bit 1: dQ (needs out, lse2 of a forward and dout
  * T[S*N][nh*64]) -> dqkv q columns; bit 2: dK, dV (needs the tables a dQ launch left in `scratch`) -> dqkv k, v columns.
  * scratch: >= bsg_op_attention_scratch_bytes bytes. */
 size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp);
-int bsg_op_attention(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
+int bsg_op_attention(void* stream, int dtype, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
                      const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
                      size_t scratch_bytes);
 

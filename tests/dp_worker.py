@@ -48,9 +48,9 @@ def run(world: int, rank: int) -> dict:
 
 def run_predict(world: int, rank: int) -> dict:
     """Sharded sliding-window predict (`predict.predict_mosaic(rank=, world=)`): overlapping windows (stride < crop, so votes
-    from different ranks land on the same pixels), a window count that does not divide by the world size.  The palette is
-    pinned to the fixed one (`create_palettes(train=False)`): `PromptModel.forward` draws a RANDOM palette per batch like the
-    reference, so two partitions of the windows consume the generator differently and are comparable only without it."""
+    from different ranks land on the same pixels), a window count that does not divide by the world size.  Palettes are
+    RANDOM per batch like the reference's (`src/model.py:134`): every rank draws the unsharded loop's sequence and window i
+    keeps row i of it, so the sharded mosaic must equal the single process's bit for bit without pinning anything."""
     import numpy as np
 
     from beach_seg_amd.config import BeachSegConfig
@@ -68,8 +68,6 @@ def run_predict(world: int, rank: int) -> dict:
     pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, 64, 64, generator=gen).numpy(),
                                  "mask": torch.randint(0, 4, (64, 64), generator=gen, dtype=torch.uint8).numpy(),
                                  "nodata": np.zeros((64, 64), bool)} for i in range(3)])
-    draw = pm.create_palettes
-    pm.create_palettes = lambda sizes, train: draw(sizes, False)
     crops = grid_crops(40, 56, 16, stride=8)  # 5 x 7 = 35 windows
     n = crops.shape[0]
     images = torch.randn(n, 3, 64, 64, generator=gen)

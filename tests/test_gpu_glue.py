@@ -14,7 +14,8 @@ import torch
 
 from beach_seg_amd import ops
 from beach_seg_amd.config import BeachSegConfig
-from beach_seg_amd.data import sample_train_aug_params, tif_image, train_aug_reference
+from beach_seg_amd.data import sample_train_aug_params, tif_image
+from oracle.train_aug_oracle import train_aug_reference
 from oracle import frontend_oracle as FO
 
 pytestmark = pytest.mark.gpu
@@ -87,11 +88,17 @@ def test_train_aug_kernel_forward_and_backward_vs_torch():
     out2, _ = ops.train_aug(img.to(DEV), None, params.to(DEV), None)  # no mask, no noise tensor
     ref2, _ = train_aug_reference(img, None, params, None)
     assert torch.allclose(out2.cpu(), ref2, rtol=1e-6, atol=1e-6)
+    # erase_mask (flags bit 5): the erased box is class 0 in the mask as well
+    pe, _ = sample_train_aug_params(B, h, w, conf, torch.Generator().manual_seed(11), erase_mask=True)
+    assert torch.equal(pe[:, 1:], params[:, 1:]) and int((pe[:, 0] & 32 != 0).sum()) == int((params[:, 3] > 0).sum())
+    _, me = ops.train_aug(img.to(DEV), mask.to(DEV), pe.to(DEV), noise.to(DEV))
+    _, mref_e = train_aug_reference(img, mask[:, 0], pe, noise)
+    assert torch.equal(me.cpu()[:, 0], mref_e) and not torch.equal(mref_e, mref)
 
 
 def test_train_aug_color_jiggle_and_sharpness_vs_torch():
     """ColorJiggle + RandomSharpness inside the device augmentation chain (`bsg_train_aug` with colour parameters) against the
-    torch statement of kornia's published formulas (`data.train_aug_reference`; kornia itself is not installable here:
+    torch statement of kornia's published formulas (`oracle/train_aug_oracle.py`; kornia itself is not installable here:
     parity unpinned), forward and the gradient wrt the prompt pixels, for every operation order class, factors on both
     sides of 1 (the clamps engage), a hue shift that wraps, sharpness factors inside and outside (0, 1), with and without
     the operations per sample."""

@@ -14,7 +14,7 @@ def rel(a, b):
     return float((a.float() - b.float()).abs().max() / b.float().abs().max())
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 192, 128), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256)])
 def test_gemm_nt_vs_torch(dtype, M, N, K):
     """Every GEMM variant: v3 (256 x 256 persistent), v2 (N <= 192), ragged M / N edges, bias epilogue."""
@@ -25,7 +25,8 @@ def test_gemm_nt_vs_torch(dtype, M, N, K):
     ref = a.double() @ w.double().t()
     out = ops.gemm_nt(a, w)
     outb = ops.gemm_nt(a, w, b)
-    tol = 1e-5 if dtype == torch.float32 else 6e-3  # bf16: output rounding 2^-9 of a value up to max|ref|
+    # 16-bit: output rounding 2^-9 (bf16) / 2^-12 (f16) of a value up to max|ref|; operands are exact in every dtype
+    tol = {torch.float32: 1e-5, torch.bfloat16: 6e-3, torch.float16: 8e-4}[dtype]
     assert rel(out, ref) < tol and rel(outb, ref + b.double()) < tol
     assert torch.isfinite(out.float()).all()
 
@@ -48,28 +49,32 @@ def _attention_reference(qkv, rel_h, rel_w, dout, S, nh, hp, wp):
     return o.detach(), rows(q.grad), rows(k.grad), rows(v.grad), float((att.max(-1).values - att.mean(-1)).max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hp,wp,S,nh,gain", [(8, 8, 3, 2, 1.0), (56, 28, 1, 2, 1.0), (56, 28, 1, 2, 6.0), (64, 32, 1, 1, 3.0)])
-def test_attention_kernels_vs_torch(hp, wp, S, nh, gain):
+def test_attention_kernels_vs_torch(hp, wp, S, nh, gain, dtype):
     """Forward, dQ, dK / dV with the decomposed rel-pos bias against autograd through the plain formula; `gain` scales q, k
     and the rel-pos tables so that the logits reach tens (peaked rows: the online-softmax rescale path, exp2 range)."""
     N, D = hp * wp, nh * 64
     g = torch.Generator(device=DEV).manual_seed(hp * 100 + wp)
     qkv = torch.randn(S * N, 3 * D, device=DEV, generator=g) * 0.8
     qkv[:, : 2 * D] *= gain
-    qkv = qkv.bfloat16()
-    dout = (torch.randn(S * N, D, device=DEV, generator=g) * 1e-3).bfloat16()
-    rel_h = (torch.randn(2 * hp - 1, 64, device=DEV, generator=g) * 0.2 * gain).bfloat16().float()
-    rel_w = (torch.randn(2 * wp - 1, 64, device=DEV, generator=g) * 0.2 * gain).bfloat16().float()
-    rc = _rel_cat(rel_h, rel_w).bfloat16().contiguous()
-    out = torch.empty(S * N, D, device=DEV, dtype=torch.bfloat16)
+    qkv = qkv.to(dtype)
+    # f16 holds 6e-5 .. 65504 at full precision: its backward runs on a gradient of order 1 (the product path scales the
+    # dgrad chain by a power of two chosen on device, rowops.hpp), bf16 takes the raw 1e-3
+    dout = (torch.randn(S * N, D, device=DEV, generator=g) * (1e-3 if dtype == torch.bfloat16 else 1.0)).to(dtype)
+    rel_h = (torch.randn(2 * hp - 1, 64, device=DEV, generator=g) * 0.2 * gain).to(dtype).float()
+    rel_w = (torch.randn(2 * wp - 1, 64, device=DEV, generator=g) * 0.2 * gain).to(dtype).float()
+    rc = _rel_cat(rel_h, rel_w).to(dtype).contiguous()
+    out = torch.empty(S * N, D, device=DEV, dtype=dtype)
     lse2 = torch.zeros(S, nh, hp * 32, device=DEV)
     dqkv = torch.zeros_like(qkv)
     ops.attention(7, qkv, rc, S, nh, hp, wp, out, lse2, ops.attention_scratch(S, nh, hp, DEV), rc.t().contiguous(), dout, dqkv)
     o, gq, gk, gv, peak = _attention_reference(qkv, rel_h, rel_w, dout, S, nh, hp, wp)
     errs = (rel(out, o), rel(dqkv[:, :D], gq), rel(dqkv[:, D:2 * D], gk), rel(dqkv[:, 2 * D:], gv))
-    print(f"[measured] attention {hp}x{wp} gain {gain}: max logit above row mean {peak:.1f}; fwd {errs[0]:.2e} dq {errs[1]:.2e} "
+    print(f"[measured] attention {dtype} {hp}x{wp} gain {gain}: max logit above row mean {peak:.1f}; fwd {errs[0]:.2e} dq {errs[1]:.2e} "
           f"dk {errs[2]:.2e} dv {errs[3]:.2e}")
     if gain > 1:
         assert peak > 20
-    assert max(errs) < 1.5e-2  # bf16 P / dS operands (2^-9) against an fp32 reference
+    # P / dS / output rounding of the operand type (2^-9 bf16, 2^-12 f16) against an fp32 reference on the same operands
+    assert max(errs) < (1.5e-2 if dtype == torch.bfloat16 else 2.5e-3)
     assert torch.isfinite(dqkv.float()).all() and torch.isfinite(lse2).all()

@@ -66,6 +66,115 @@ def test_training_step_autograd_path_equals_fused_engine_and_oracle():
         assert torch.equal(eng.params[i].cpu(), P0[i]) and int(eng.steps[i]) == 0
 
 
+def test_validation_after_training_sees_the_updated_prompts():
+    """`prepare_prompt`'s no-grad path gathers from a cached stack of the prompt Parameters; the cache must follow
+    in-place updates (`optimizer.step()` keeps the list and the Parameter objects): after `fit_step`, `validation_step` /
+    `forward` must run on the NEW prompt pixels, as the reference's `torch.stack` of the live Parameters does
+    (`src/model.py:197`)."""
+    geo = SegGptGeometry.tiny()
+    net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float32)
+    conf = BeachSegConfig(batch_size=2, checkpoint="synthetic:tiny", precision="32-true", inpt_size=64, crop_size=64, lr=0.05)
+    pm = PromptModel(conf, model=net)
+    pm.create_trainable_params(_prompts(2, 64))
+    opt = pm.configure_optimizers()["optimizer"]
+    g = torch.Generator().manual_seed(5)
+    batch = {"image": ml_util.normalize(torch.rand(2, 3, 64, 64, generator=g)).to(DEV),
+             "mask": torch.randint(1, 4, (2, 1, 64, 64), generator=g, dtype=torch.uint8).to(DEV),
+             "crop_idx": torch.tensor([0, 1])}
+    pal, _ = pm.create_palette(2, train=False)
+    with torch.no_grad():
+        before, _ = pm.prepare_prompt(batch["crop_idx"], pal, train=False)  # fills the cache
+    pm.fit_step(batch, opt)
+    pm.fit_step(batch, opt)
+    live = ml_util.normalize(torch.stack([p.detach() for p in pm.prompt_params_list]))
+    with torch.no_grad():
+        after, _ = pm.prepare_prompt(batch["crop_idx"], pal, train=False)
+        after_dev, _ = pm.prepare_prompt(batch["crop_idx"].to(DEV), pal, train=False)  # the predict loop's device-index form
+    assert not torch.equal(before["image"], after["image"])
+    assert torch.equal(after["image"], live) and torch.equal(after_dev["image"], live)
+    # an edit the version counters cannot see (.data assignment) needs the explicit hook
+    pm.prompt_params_list[0].data = torch.zeros_like(pm.prompt_params_list[0].data)
+    pm.invalidate_prompt_cache()
+    with torch.no_grad():
+        z, _ = pm.prepare_prompt(torch.tensor([0]), pal[:1], train=False)
+    assert torch.equal(z["image"], ml_util.normalize(torch.zeros(1, 3, 64, 64, device=DEV)))
+    # and a validation loss computed after training differs from the one before it
+    pm2 = PromptModel(conf, model=net)
+    pm2.create_trainable_params(_prompts(2, 64))
+    l0 = pm2.validation_step(batch)
+    pm2.palette_g.manual_seed(conf.seed + 1)
+    opt2 = pm2.configure_optimizers()["optimizer"]
+    pm2.fit_step(batch, opt2)
+    pm2.palette_g.manual_seed(conf.seed + 1)
+    l1 = pm2.validation_step(batch)
+    assert torch.isfinite(l0) and torch.isfinite(l1) and l0.item() != l1.item()
+
+
+def test_engine_step_from_class_ids_equals_step_on_materialised_images():
+    """`PromptTrainEngine.step_ids` (colourisation kernel + id-based loss: SURVEY 8(a) row 4 fused into the step) against
+    `step` on the explicitly colourised + normalised images: bit-identical loss and parameters."""
+    geo = SegGptGeometry.tiny()
+    net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float32)
+    g = torch.Generator().manual_seed(8)
+    P0 = torch.rand(3, 3, 64, 64, generator=g)
+    pix = ml_util.normalize(torch.rand(2, 3, 64, 64, generator=g)).to(DEV)
+    lab_ids = torch.randint(0, 4, (2, 1, 64, 64), generator=g, dtype=torch.uint8).to(DEV)
+    pm_ids = torch.randint(0, 4, (2, 64, 64), generator=g, dtype=torch.uint8).to(DEV)
+    pal = torch.randint(0, 256, (2, 4, 3), generator=g, dtype=torch.uint8)
+    pal[:, 0] = 0
+    pn = PromptModel._palette_norm(pal).to(DEV)
+    pal = pal.to(DEV)
+    idx = torch.tensor([2, 0], device=DEV)
+    e1 = PromptTrainEngine(net, P0, lr=1e-2)
+    e2 = PromptTrainEngine(net, P0, lr=1e-2)
+    for _ in range(2):
+        l1 = e1.step(pix, ops.mask_rgb_norm(pal, lab_ids), lab_ids != 0, idx, ops.mask_rgb_norm(pal, pm_ids))
+        l2 = e2.step_ids(pix, lab_ids, pal, pn, idx, pm_ids)
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2) and torch.equal(e1.params, e2.params)
+
+
+def test_f16_overflow_guard_skips_the_step_and_backs_off():
+    """The f16 dgrad chain runs on S * gradient in IEEE half; a non-finite prompt gradient must not reach AdamW.  Engine:
+    the device-side flag zeroes the `touched` mask (parameters, moments and step counts untouched, `skipped_steps` + 1) and
+    the next backward runs with 4x more headroom; autograd path: `last_backward_overflowed()` lets `fit_step` skip
+    `optimizer.step()` the way GradScaler does."""
+    geo = SegGptGeometry.tiny()
+    net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float16)
+    g = torch.Generator().manual_seed(8)
+    P0 = torch.rand(3, 3, 64, 64, generator=g)
+    pix = ml_util.normalize(torch.rand(2, 3, 64, 64, generator=g)).to(DEV)
+    lab = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    pmc = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    yes = torch.ones(2, 1, 64, 64, dtype=torch.bool, device=DEV)
+    idx = torch.tensor([2, 0], device=DEV)
+    eng = PromptTrainEngine(net, P0, lr=1e-2)
+    eng.step(pix, lab, yes, idx, pmc)
+    st = net.grad_overflow_state(2).clone()
+    assert st.tolist()[:2] == [0, 0] and int(eng.skipped_steps) == 0
+    before = (eng.params.clone(), eng.exp_avg.clone(), eng.steps.clone())
+    bad = pix.clone()
+    bad[0, 0, 3, 3] = float("inf")  # non-finite activations saved by the forward -> non-finite dgrad
+    eng.step(bad, lab, yes, idx, pmc)
+    torch.cuda.synchronize()
+    st = net.grad_overflow_state(2)
+    assert st[0].item() == 1 and st[1].item() == 2 and st[3].item() == 1 and int(eng.skipped_steps) == 1
+    assert torch.equal(eng.params, before[0]) and torch.equal(eng.exp_avg, before[1]) and torch.equal(eng.steps, before[2])
+    eng.step(pix, lab, yes, idx, pmc)  # clean again: flag clears, the back-off stays, the step is applied
+    st = net.grad_overflow_state(2)
+    assert st[0].item() == 0 and st[1].item() == 2 and int(eng.skipped_steps) == 1
+    assert not torch.equal(eng.params, before[0]) and torch.isfinite(eng.params).all()
+    # autograd boundary
+    p = P0[:2].to(DEV).requires_grad_(True)
+    out = net(pixel_values=bad, prompt_pixel_values=p, prompt_masks=pmc)
+    ops.seggpt_loss(out.pred_masks, lab, yes, 0.01, "reference").backward()
+    assert net.last_backward_overflowed()
+    p.grad = None
+    out = net(pixel_values=pix, prompt_pixel_values=p, prompt_masks=pmc)
+    ops.seggpt_loss(out.pred_masks, lab, yes, 0.01, "reference").backward()
+    assert not net.last_backward_overflowed() and torch.isfinite(p.grad).all()
+
+
 def test_validation_forward_and_predict_mosaic():
     geo = SegGptGeometry.tiny()
     net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float32)

@@ -275,6 +275,47 @@ def test_loss_both_variants_vs_reference(golden_dir):
     assert torch.isnan(l0)
 
 
+def test_mask_colourisation_kernel_bit_exact_and_loss_from_class_ids(golden_dir):
+    """`torch_apply_mask_rgb` (`src/util/ml_util.py:114-132`) and `normalize` (`src/data.py:345`)
+    as ONE HIP kernel, bit-exact against the reference's own output; and the loss taking class ids + normalised palette
+    (`bsg_loss_fwd_bwd_ids`) bit-identical to the loss on the materialised label image (`src/model.py:238-239, 255`)."""
+    from beach_seg_amd import ml_util
+
+    rec = np.load(golden_dir / "wrapper.npz")
+    pal, mask = torch.from_numpy(rec["rand_palette_seed42"]).to(DEV), torch.from_numpy(rec["mask"]).to(DEV)
+    rgb = ml_util.torch_apply_mask_rgb(pal, mask)  # mean 0 / std 1 through the same kernel
+    assert rgb.dtype == torch.float32 and np.array_equal(rgb.cpu().numpy(), rec["apply_mask_rgb"])
+    assert np.array_equal(ml_util.torch_apply_mask_rgb(pal, mask[:, 0]).cpu().numpy(), rec["apply_mask_rgb"])  # (B,H,W) ids
+    mean = np.array(ops.IMAGE_MEAN, np.float32).reshape(1, 3, 1, 1)
+    std = np.array(ops.IMAGE_STD, np.float32).reshape(1, 3, 1, 1)
+    want = (rec["apply_mask_rgb"] - mean) / std  # float32 numpy = the reference's CPU arithmetic
+    got = ops.mask_rgb_norm(pal, mask)
+    assert np.array_equal(got.cpu().numpy(), want)
+    # ragged plane (h*w not a multiple of 4: scalar tail path) and K = 256
+    g = torch.Generator().manual_seed(3)
+    pal2 = torch.randint(0, 256, (2, 256, 3), generator=g, dtype=torch.uint8)
+    ids2 = torch.randint(0, 256, (2, 7, 9), generator=g, dtype=torch.uint8)
+    want2 = ((O.apply_mask_rgb(pal2, ids2).numpy() - mean) / std).astype(np.float32)
+    assert np.array_equal(ops.mask_rgb_norm(pal2.to(DEV), ids2.to(DEV)).cpu().numpy(), want2)
+    with pytest.raises(ValueError):
+        ops.mask_rgb_norm(pal.float(), mask)
+    # loss from class ids == loss on the materialised normalised label image, bit for bit (value and gradient)
+    pred = torch.from_numpy(rec["decode_pred"]).to(DEV)
+    pn = torch.from_numpy(rec["pal_norm"]).to(DEV)
+    for variant in ("reference", "per_sample"):
+        for beta in (0.01, 0.5):
+            p1 = pred.clone().requires_grad_(True)
+            l1 = ops.seggpt_loss(p1, got, mask != 0, beta, variant)
+            l1.backward()
+            p2 = pred.clone().requires_grad_(True)
+            l2 = ops.seggpt_loss_ids(p2, mask, pn, beta, variant)
+            l2.backward()
+            assert torch.equal(l1, l2) and torch.equal(p1.grad, p2.grad), (variant, beta)
+    ref = O.seggpt_loss(pred.cpu(), torch.from_numpy(want), torch.from_numpy(rec["mask"] != 0), 0.01, "reference")
+    assert abs(l2.item() - ops.seggpt_loss_ids(pred, mask, pn, 0.5, "per_sample").item()) == 0
+    assert abs(ops.seggpt_loss_ids(pred, mask, pn, 0.01, "reference").item() - ref.item()) < 2e-6 * abs(ref.item())
+
+
 def test_decode_bit_exact_including_near_ties(golden_dir):
     rec = np.load(golden_dir / "wrapper.npz")
     pred = torch.from_numpy(rec["decode_pred"]).to(DEV)

@@ -32,7 +32,14 @@ def test_palette_and_mask_colouring_vs_reference(golden_dir):
     assert np.array_equal(np.array(ml_util.build_palette(3)), rec["build_palette_3"])
     assert np.array_equal(np.array(ml_util.build_palette(7)), rec["build_palette_7"])
     pal = torch.from_numpy(rec["rand_palette_seed42"])
-    assert np.array_equal(ml_util.torch_apply_mask_rgb(pal, torch.from_numpy(rec["mask"])).numpy(), rec["apply_mask_rgb"])
+    # the colourisation itself is a HIP kernel (`bsg_mask_rgb_norm`, bit-exact in tests/test_gpu_parity.py): no CPU path
+    from beach_seg_amd._native import NativeError
+    from beach_seg_amd.model import PromptModel
+
+    with pytest.raises(NativeError):
+        ml_util.torch_apply_mask_rgb(pal, torch.from_numpy(rec["mask"]))
+    # normalised palette: formed on the host in float32 with true divisions = the reference's CPU bits (src/model.py:221-229)
+    assert np.array_equal(PromptModel._palette_norm(pal).numpy(), rec["pal_norm"])
     torch.manual_seed(42)  # the reference draws from the global RNG (src/util/ml_util.py:102-108)
     assert np.array_equal(ml_util.generate_random_rgb_palette(4, 3, "cpu").numpy(), rec["rand_palette_seed42"])
     x = torch.rand(2, 3, 4, 4)
@@ -101,7 +108,8 @@ def test_f1_macro_average_follows_torchmetrics_rules():
 
 
 def test_train_aug_parameters_and_reference_semantics():
-    from beach_seg_amd.data import sample_train_aug_params, train_aug_reference
+    from beach_seg_amd.data import sample_train_aug_params
+    from oracle.train_aug_oracle import train_aug_reference
 
     conf = BeachSegConfig(vertical_flip=0.5, horizontal_flip=0.5, erasing_p=0.6, gauss_p=0.5)
     g = torch.Generator().manual_seed(3)
@@ -127,13 +135,21 @@ def test_train_aug_parameters_and_reference_semantics():
     out.sum().backward()
     g0 = (torch.ones(3, 8, 10) / std); g0[:, 1:3, 2:5] = 0
     assert torch.allclose(img.grad[0], g0.flip(-2)) and torch.allclose(img.grad[1], (torch.ones(3, 8, 10) / std))
+    # erase_mask (flags bit 5): the erased box becomes class 0 in the mask too; the sampler sets the bit on erased samples only
+    prm2 = prm.clone(); prm2[0, 0] |= 32
+    _, mo2 = train_aug_reference(img.detach(), mask, prm2, nz)
+    want = mask[0].flip(-2).clone(); want[1:3, 2:5] = 0
+    assert torch.equal(mo2[0], want) and torch.equal(mo2[1], mo[1])
+    pe, _ = sample_train_aug_params(16, 32, 48, conf, torch.Generator().manual_seed(3), erase_mask=True)
+    assert torch.equal(pe[:, 1:], params[:, 1:]) and torch.equal((pe[:, 0] & 32) != 0, params[:, 3] > 0) and torch.equal(pe[:, 0] & 31, params[:, 0])
 
 
 def test_train_aug_color_parameters_and_statement():
     """The colour half of the sampler (ColorJiggle / RandomSharpness ranges of src/config.py:52-58 through kornia's documented
     generators) and the torch statement of the two operations: identity factors are the identity, HSV round-trips, a half-turn
     hue shift applied twice returns the image, sharpness factor 1 is the identity and factor 0 the blurred interior."""
-    from beach_seg_amd.data import _color_jiggle, _hsv_to_rgb, _rgb_to_hsv, _sharpness, sample_train_aug_params
+    from beach_seg_amd.data import sample_train_aug_params
+    from oracle.train_aug_oracle import _color_jiggle, _hsv_to_rgb, _rgb_to_hsv, _sharpness
 
     conf = BeachSegConfig(sharpness_p=0.5)
     params, noise, color = sample_train_aug_params(64, 16, 16, conf, torch.Generator().manual_seed(1), with_color=True)
@@ -193,9 +209,12 @@ def _dp_worker(rank, world, port, q):
     from beach_seg_amd.predict import reduce_vote_counters
     votes = torch.zeros(3, 4, 2, dtype=torch.uint8)
     votes[0, 0, 0], votes[1, 2, 1], votes[2, 3, 0] = 200 + rank, 7 * rank, 255
+    votes[0, 1, 1] = 200 if rank == 0 else 100  # neither rank wraps on its own; the SUM across ranks crosses 255 -> 44
+    votes[0, 2, 0] = 255 if rank == 0 else 1    # exactly 256 votes -> 0, as the single process's uint8 `+= 1` gives
     reduce_vote_counters(votes)
     assert int(votes[0, 0, 0]) == (200 + 201) % 256 and int(votes[1, 2, 1]) == 7 and int(votes[2, 3, 0]) == (255 + 255) % 256
-    assert int(votes.sum()) == 145 + 7 + 254
+    assert int(votes[0, 1, 1]) == (200 + 100) % 256 == 44 and int(votes[0, 2, 0]) == 0
+    assert int(votes.sum()) == 145 + 7 + 254 + 44
     q.put((rank, flat.clone()))
     dist.barrier()
     dist.destroy_process_group()
