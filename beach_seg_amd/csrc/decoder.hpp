@@ -1,6 +1,7 @@
-// SegGPT decoder head on gfx950 (HF:modeling_seggpt.py:525-546): direct 3x3 convolution 64->64 over the NHWC
+// SegGPT decoder head on gfx950 (HF:modeling_seggpt.py:525-546): direct 3x3 convolution C->C (C = decoder_hidden_size: 64 in
+// the reference checkpoint, 128 in BASELINE config 5) over the NHWC
 // feature map (no im2col: nine shifted NT-GEMM steps over an LDS halo tile), fused in ONE pass with bias,
-// per-pixel LayerNorm(64) (wavefront-lane reductions), exact GELU and the 1x1 head (64->3), and the matching
+// per-pixel LayerNorm(C) (wavefront-lane reductions), exact GELU and the 1x1 head (64->3), and the matching
 // backward: a per-pixel kernel through head/GELU/LayerNorm and the same conv kernel with flipped weights for dgrad.
 #pragma once
 #include "common.hpp"
@@ -8,116 +9,131 @@
 enum ConvMode { CONV_FWD_FUSED = 0, CONV_PLAIN = 1 };
 
 struct ConvArgs {
-  const void* in;     // T NHWC [B][H][W][64]
-  const void* w;      // T [64 co][9 taps][64 ci]
-  const float* bias;  // [64] or nullptr (CONV_PLAIN)
+  const void* in;     // T NHWC [B][H][W][DC], DC = decoder_hidden_size (64 or 128)
+  const void* w;      // T [DC co][9 taps][DC ci]
+  const float* bias;  // [DC] or nullptr (CONV_PLAIN)
   void* out;          // T NHWC: conv output (pre-LN) in FUSED mode (may be nullptr), plain output otherwise
-  const float* ln_g; const float* ln_b;  // [64]
-  const float* head_w;                   // [3][64]
+  const float* ln_g; const float* ln_b;  // [DC]
+  const float* head_w;                   // [3][DC]
   const float* head_b;                   // [3]
   float* pred;                           // fp32 NCHW [B][3][H][W]
   int H, W;
   float eps;
-  int ty0;  // first 16-row output tile (dgrad over a row window)
+  int ty0;  // first output row / 16 (dgrad over a row window: token rows)
 };
 
-// Workgroup = 16 x 32 output pixels; wave w owns rows 4w .. 4w+3 (128 pixels) x 64 output channels (4 x 8 MFMA 16x16
-// tiles): every weight fragment fetched (L1/L2: the 73 KB filter bank is re-read by every wave) feeds 8 MFMAs.
-constexpr int CONV_TR = 16, CONV_RW = 4, CONV_HALO = (CONV_TR + 2) * 34;  // tile rows, rows per wave, halo pixels
-template <typename T, int MODE>
+// Workgroup = TR x 32 output pixels; wave w owns rows RW*w .. RW*w + RW-1 x all DC output channels (DC/16 x 2 RW MFMA 16x16
+// tiles): every weight fragment fetched (L1/L2: the filter bank is re-read by every wave) feeds 2 RW MFMAs.  DC = 64 (the
+// reference checkpoint, HF:configuration_seggpt.py decoder_hidden_size): TR = 16, RW = 4, one pass over the 64 input channels.
+// DC = 128 (BASELINE config 5): TR = 8, RW = 2 (the 8 x 4 accumulator tiles fill 128 registers) and the contraction runs in
+// two passes of 64 input channels through the same 128-byte-per-pixel halo tile.  CONV_TR (16 rows = one token row) is the
+// unit of `ty0` for every variant.
+constexpr int CONV_TR = 16;
+template <int DC> struct ConvGeo {
+  static_assert(DC == 64 || DC == 128, "decoder width: 64 or 128 channels");
+  static constexpr int RW = DC == 64 ? 4 : 2, TR = 4 * RW, HALO = (TR + 2) * 34, NO = DC / 16, HALVES = DC / 64;
+};
+template <typename T, int MODE, int DC>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
-  constexpr int EPC = Traits<T>::EPC, CPP = 64 / EPC;  // chunks per pixel: 8 (bf16) / 16 (f32)
-  constexpr int PB = 64 * sizeof(T);                   // bytes per pixel
-  constexpr int KS = CPP / 4;                          // 16x16 k-steps per tap
-  constexpr int NM = 2 * CONV_RW;                      // pixel tiles per wave: (row, x half)
+  typedef ConvGeo<DC> G;
+  constexpr int EPC = Traits<T>::EPC, CPP = 64 / EPC;  // chunks per pixel of one 64-channel pass: 8 (16-bit) / 16 (f32)
+  constexpr int PB = 64 * sizeof(T);                   // LDS bytes per pixel (one pass)
+  constexpr int GPB = DC * sizeof(T);                  // global bytes per pixel
+  constexpr int KS = CPP / 4;                          // 16x16 k-steps per tap and pass
+  constexpr int NM = 2 * G::RW;                        // pixel tiles per wave: (row, x half)
+  constexpr int NO = G::NO;                            // output-channel tiles
   extern __shared__ __attribute__((aligned(16))) char halo[];  // [TR + 2][34] pixels x PB, chunk-swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int x0 = blockIdx.x * 32, y0 = (blockIdx.y + a.ty0) * CONV_TR, b = blockIdx.z;
-  const char* img = (const char*)a.in + (long)b * a.H * a.W * PB;
-
-  for (int i = tid; i < CONV_HALO * CPP; i += 256) {
-    const int pix = i / CPP, ch = i % CPP;
-    const int hy = pix / 34, hx = pix % 34, y = y0 + hy - 1, x = x0 + hx - 1;
-    Chunk v;
-#pragma unroll
-    for (int j = 0; j < EPC; ++j) v[j] = from_f32<T>(0.f);
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = *(const Chunk*)(img + ((long)y * a.W + x) * PB + ch * 16);
-    *(Chunk*)(halo + pix * PB + ((ch ^ (pix & (CPP - 1))) << 4)) = v;
-  }
-  __syncthreads();
+  const int x0 = blockIdx.x * 32, y0 = a.ty0 * CONV_TR + blockIdx.y * G::TR, b = blockIdx.z;
+  const char* img = (const char*)a.in + (long)b * a.H * a.W * GPB;
 
   const int frow = lane & 15, fchunk = lane >> 4;
-  f32x4 acc[4][NM];  // [ni][mi]
+  f32x4 acc[NO][NM];  // [ni][mi]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NO; ++i)
 #pragma unroll
     for (int j = 0; j < NM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#pragma unroll 1
+  for (int half = 0; half < G::HALVES; ++half) {
+    if (half) __syncthreads();  // every wave is done with the previous pass's halo
+    for (int i = tid; i < G::HALO * CPP; i += 256) {
+      const int pix = i / CPP, ch = i % CPP;
+      const int hy = pix / 34, hx = pix % 34, y = y0 + hy - 1, x = x0 + hx - 1;
+      Chunk v;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) v[j] = from_f32<T>(0.f);
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = *(const Chunk*)(img + ((long)y * a.W + x) * GPB + half * PB + ch * 16);
+      *(Chunk*)(halo + pix * PB + ((ch ^ (pix & (CPP - 1))) << 4)) = v;
+    }
+    __syncthreads();
+
 #pragma unroll 1  // rolled: with 128 accumulator registers a fully unrolled tap loop hoists operand loads into spills
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dy = tap / 3, dx = tap - 3 * dy;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int c = fchunk + 4 * ks;
-      Chunk fa[NM], fw[4];
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = fchunk + 4 * ks;
+        Chunk fa[NM], fw[NO];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        fw[i] = *(const Chunk*)((const char*)a.w + (((long)(i * 16 + frow) * 9 + tap) * 64) * sizeof(T) + c * 16);
+        for (int i = 0; i < NO; ++i)
+          fw[i] = *(const Chunk*)((const char*)a.w + (((long)(i * 16 + frow) * 9 + tap) * DC + half * 64) * sizeof(T) + c * 16);
 #pragma unroll
-      for (int i = 0; i < NM; ++i) {
-        const int pix = (CONV_RW * wave + (i >> 1) + dy) * 34 + (i & 1) * 16 + frow + dx;
-        fa[i] = *(const Chunk*)(halo + pix * PB + ((c ^ (pix & (CPP - 1))) << 4));
+        for (int i = 0; i < NM; ++i) {
+          const int pix = (G::RW * wave + (i >> 1) + dy) * 34 + (i & 1) * 16 + frow + dx;
+          fa[i] = *(const Chunk*)(halo + pix * PB + ((c ^ (pix & (CPP - 1))) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NO; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < NM; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
       }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < NM; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
     }
   }
 
-  // acc[ni][mi][r]: pixel (y0 + 4*wave + (mi>>1), x0 + (mi&1)*16 + frow), channel ni*16 + 4*fchunk + r
+  // acc[ni][mi][r]: pixel (y0 + RW*wave + (mi>>1), x0 + (mi&1)*16 + frow), channel ni*16 + 4*fchunk + r
 #pragma unroll
   for (int mi = 0; mi < NM; ++mi) {
-    const int y = y0 + CONV_RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + frow;
+    const int y = y0 + G::RW * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + frow;
     const long pix = ((long)b * a.H + y) * a.W + x;
     if (MODE == CONV_PLAIN) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NO; ++ni) {
         const f32x4 v = acc[ni][mi];
-        *(typename Traits<T>::Vec4*)((T*)a.out + pix * 64 + ni * 16 + 4 * fchunk) = pack4<T>(v[0], v[1], v[2], v[3]);
+        *(typename Traits<T>::Vec4*)((T*)a.out + pix * DC + ni * 16 + 4 * fchunk) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
     } else {
-      f32x4 v[4];
+      f32x4 v[NO];
       float s = 0.f;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NO; ++ni) {
         v[ni] = acc[ni][mi] + *(const f32x4*)(a.bias + ni * 16 + 4 * fchunk);
         if (a.out)
-          *(typename Traits<T>::Vec4*)((T*)a.out + pix * 64 + ni * 16 + 4 * fchunk) =
+          *(typename Traits<T>::Vec4*)((T*)a.out + pix * DC + ni * 16 + 4 * fchunk) =
               pack4<T>(v[ni][0], v[ni][1], v[ni][2], v[ni][3]);
         s += v[ni][0] + v[ni][1] + v[ni][2] + v[ni][3];
       }
-      // the 64 channels of a pixel live in the 4 lanes {frow, frow+16, frow+32, frow+48}
+      // the DC channels of a pixel live in the 4 lanes {frow, frow+16, frow+32, frow+48}
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      const float mean = s * (1.f / 64.f);
+      const float mean = s * (1.f / DC);
       float q = 0.f;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < NO; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[ni][r] -= mean; q += v[ni][r] * v[ni][r]; }
       q += __shfl_xor(q, 16, 64);
       q += __shfl_xor(q, 32, 64);
-      const float rstd = rsqrtf(q * (1.f / 64.f) + a.eps);
+      const float rstd = rsqrtf(q * (1.f / DC) + a.eps);
       float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
+      for (int ni = 0; ni < NO; ++ni) {
         const int c0 = ni * 16 + 4 * fchunk;
         const f32x4 g = *(const f32x4*)(a.ln_g + c0), be = *(const f32x4*)(a.ln_b + c0);
-        const f32x4 w0 = *(const f32x4*)(a.head_w + c0), w1 = *(const f32x4*)(a.head_w + 64 + c0),
-                    w2 = *(const f32x4*)(a.head_w + 128 + c0);
+        const f32x4 w0 = *(const f32x4*)(a.head_w + c0), w1 = *(const f32x4*)(a.head_w + DC + c0),
+                    w2 = *(const f32x4*)(a.head_w + 2 * DC + c0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t = gelu_f(v[ni][r] * rstd * g[r] + be[r]);
@@ -356,18 +372,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ring_kernel(ConvRingArgs ra) {
   }
 }
 
-// Per-pixel backward of head (1x1) -> GELU -> LayerNorm(64): dpred (fp32 NCHW) + saved conv output -> d conv out.
-// Four lanes per pixel (16 channels each, 32/64 contiguous bytes per lane), reductions by two xor-shuffles.
-template <typename T>
+// Per-pixel backward of head (1x1) -> GELU -> LayerNorm(DC): dpred (fp32 NCHW) + saved conv output -> d conv out.
+// DC / 16 lanes per pixel (16 channels each, 32/64 contiguous bytes per lane), reductions by xor-shuffles inside the group.
+template <typename T, int DC>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ conv_out,
                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b,
                                                         const float* __restrict__ head_w, T* __restrict__ dconv, int B,
                                                         int H, int W, float eps, int row0, const float* gscale) {
+  constexpr int LP = DC / 16;  // lanes per pixel: 4 or 8
   const long hw = (long)H * W, win = (long)(H - row0) * W, total = (long)B * win;  // rows [row0, H) of every image
   const long gid = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const long pl = gid >> 2;
-  const int c0 = (int)(gid & 3) * 16;
-  if (pl >= total) return;  // total*4 is a multiple of 64: whole waves exit together
+  const long pl = gid / LP;
+  const int c0 = (int)(gid % LP) * 16;
+  if (pl >= total) return;  // total*LP is a multiple of 64: whole waves exit together
   const int b = pl / win;
   const long yx = (long)row0 * W + pl % win;
   const long p = (long)b * hw + yx;
@@ -375,9 +392,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   const float d0 = dpred[(long)b * 3 * hw + yx] * gs, d1 = dpred[(long)b * 3 * hw + hw + yx] * gs,
               d2 = dpred[(long)b * 3 * hw + 2 * hw + yx] * gs;
   typedef typename Traits<T>::Vec4 V4;
-  V4* dst = (V4*)(dconv + p * 64 + c0);
+  V4* dst = (V4*)(dconv + p * DC + c0);
   float v[16], g[16];
-  const V4* src = (const V4*)(conv_out + p * 64 + c0);
+  const V4* src = (const V4*)(conv_out + p * DC + c0);
+  auto group_sum = [](float x) {
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    if (LP == 8) x += __shfl_xor(x, 4, 64);
+    return x;
+  };
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -385,32 +408,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[4 * i + j] = to_f32(t[j]); s += v[4 * i + j]; }
   }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  const float mean = s * (1.f / 64.f);
+  const float mean = group_sum(s) * (1.f / DC);
   float q = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) { v[c] -= mean; q += v[c] * v[c]; }
-  q += __shfl_xor(q, 1, 64);
-  q += __shfl_xor(q, 2, 64);
-  const float rstd = rsqrtf(q * (1.f / 64.f) + eps);
+  const float rstd = rsqrtf(group_sum(q) * (1.f / DC) + eps);
   float mg = 0.f, mgx = 0.f;
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     v[c] *= rstd;  // xhat
     const float gm = ln_g[c0 + c];
     const float y = v[c] * gm + ln_b[c0 + c];
-    const float dgl = d0 * head_w[c0 + c] + d1 * head_w[64 + c0 + c] + d2 * head_w[128 + c0 + c];
+    const float dgl = d0 * head_w[c0 + c] + d1 * head_w[DC + c0 + c] + d2 * head_w[2 * DC + c0 + c];
     g[c] = dgl * gelu_grad_f(y) * gm;
     mg += g[c];
     mgx += g[c] * v[c];
   }
-  mg += __shfl_xor(mg, 1, 64);
-  mg += __shfl_xor(mg, 2, 64);
-  mgx += __shfl_xor(mgx, 1, 64);
-  mgx += __shfl_xor(mgx, 2, 64);
-  mg *= (1.f / 64.f);
-  mgx *= (1.f / 64.f);
+  mg = group_sum(mg) * (1.f / DC);
+  mgx = group_sum(mgx) * (1.f / DC);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     dst[i] = pack4<T>(rstd * (g[4 * i] - mg - v[4 * i] * mgx), rstd * (g[4 * i + 1] - mg - v[4 * i + 1] * mgx),

@@ -36,6 +36,7 @@ struct GemmArgs {
   int tokens;  // tokens per stream (Hp * Wp)
   int wp;      // token-grid width
   int himg, wimg;  // canvas pixels
+  int feat_lg;     // log2 of the decoder feature width (6: 64 channels, 7: 128) -- NHWC feature map addressing of A_FEAT / EPI_FEAT
   int batch;       // B (streams of kind 0)
   // epilogue
   const float* bias;
@@ -98,8 +99,8 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
       if (EPI == EPI_FEAT) {
         const int b = m / g.tokens, t = m % g.tokens;
         const int ph = t / g.wp, pw = t % g.wp;
-        const int p1 = col >> 10, p2 = (col >> 6) & 15, c = col & 63;
-        off = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
+        const int lg = g.feat_lg, p1 = col >> (lg + 4), p2 = (col >> lg) & 15, c = col & ((1 << lg) - 1);
+        off = ((((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) << lg) + c;
       } else {
         const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
         off = orow * g.ldo + col;
@@ -156,11 +157,11 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         const f32x4 r = *(const f32x4*)((const float*)g.aux + ((long)kind * g.tokens + t) * g.ldaux + n);
         *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
       } else if (EPI == EPI_FEAT) {
-        // n = (p1*16 + p2)*64 + c  ->  pixel (ph*16 + p1, pw*16 + p2), channel c   (HF:559-572)
+        // n = (p1*16 + p2)*C + c  ->  pixel (ph*16 + p1, pw*16 + p2), channel c, C = decoder_hidden_size   (HF:559-572)
         const int b = m / g.tokens, t = m % g.tokens;
         const int ph = t / g.wp, pw = t % g.wp;
-        const int p1 = n >> 10, p2 = (n >> 6) & 15, c = n & 63;
-        const long o = (((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) * 64 + c;
+        const int lg = g.feat_lg, p1 = n >> (lg + 4), p2 = (n >> lg) & 15, c = n & ((1 << lg) - 1);
+        const long o = ((((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) << lg) + c;
         *(typename Traits<T>::Vec4*)((T*)g.out + o) = pack4<T>(v[0], v[1], v[2], v[3]);
       } else if (EPI == EPI_GELU_BWD) {
         const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     } else {  // NHWC feature map (B, himg, wimg, 64): row m = (b, ph, pw) starts at pixel (ph*16, pw*16)
       const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
       const int ph = t / g.wp, pw = t % g.wp;
-      base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+      base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) << g.feat_lg;
     }
     a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
     int n = n0 + r;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     const long k0 = (long)kt * BK;
     long ka;
     if (AMODE == A_PLAIN) ka = k0;
-    else ka = (k0 >> 10) * ((long)g.wimg * 64) + (k0 & 1023);  // k = p1*1024 + (p2*64 + c)
+    else ka = (k0 >> (g.feat_lg + 4)) * ((long)g.wimg << g.feat_lg) + (k0 & ((16 << g.feat_lg) - 1));  // k = p1*16C + (p2*C + c)
     char* la = lds_a0 + buf * 16384 + wave * 4096;
     char* lw = lds_w0 + buf * 16384 + wave * 4096;
 #pragma unroll
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
     } else {
       const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
       const int ph = t / g.wp, pw = t % g.wp;
-      base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+      base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) << g.feat_lg;
     }
     a_src[i] = (const char*)g.A + base * sizeof(T) + sc * 16;
   }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
     const long k0 = (long)kt * BK;
     long ka;
     if (AMODE == A_PLAIN) ka = k0;
-    else ka = (k0 >> 10) * ((long)g.wimg * 64) + (k0 & 1023);
+    else ka = (k0 >> (g.feat_lg + 4)) * ((long)g.wimg << g.feat_lg) + (k0 & ((16 << g.feat_lg) - 1));
     char* la = smem + st * STAGE + wave * 4096;
     char* lw = smem + st * STAGE + 32768 + wave * 2048;
 #pragma unroll
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
         } else {
           const int b = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
           const int ph = t / g.wp, pw = t % g.wp;
-          base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+          base = (((long)b * g.himg + ph * 16) * g.wimg + pw * 16) << g.feat_lg;
         }
         src[q][i] = (const char*)g.A + base * sizeof(T) + sc * 16;
       } else {
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   auto issue = [&](int q, int kt, int buf) {
     const long k0 = (long)kt * BK;
     long koff = k0;
-    if (AMODE == A_FEAT && (q == 0 || q == 3)) koff = (k0 >> 10) * ((long)g.wimg * 64) + (k0 & 1023);
+    if (AMODE == A_FEAT && (q == 0 || q == 3)) koff = (k0 >> (g.feat_lg + 4)) * ((long)g.wimg << g.feat_lg) + (k0 & ((16 << g.feat_lg) - 1));
 #pragma unroll
     for (int i = 0; i < 2; ++i) glds16(src[q][i] + koff * sizeof(T), smem + buf * BUF + ldsoff[q][i]);
   };
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
           } else {
             const int bb = m / g.a_rpg, t = g.t_off + m % g.a_rpg;
             const int ph = t / g.wp, pw = t % g.wp;
-            base = (((long)bb * g.himg + ph * 16) * g.wimg + pw * 16) * 64;
+            base = (((long)bb * g.himg + ph * 16) * g.wimg + pw * 16) << g.feat_lg;
           }
           sp = (const char*)g.A + base * sizeof(T) + sc * 16;
         } else {

@@ -78,7 +78,7 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
   Plan p;
   const size_t es = m->es, N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads,
                mlp = m->c.mlp_dim, npad = m->npad, hp = m->hp, nt = m->c.num_taps;
-  const size_t HW = (size_t)m->c.canvas_h * m->c.canvas_w;
+  const size_t HW = (size_t)m->c.canvas_h * m->c.canvas_w, dc = m->c.decoder_hidden;
   const size_t r2 = 2 * (size_t)B * N, r1 = (size_t)B * N;
   const size_t ek = m->c.embed_split ? 3 : 1;  // split-precision patch embed: K = 3 x 768 ([hi | hi | lo] x [W_hi | W_lo | W_hi])
   p.add("patch_a", -1, r2 * 768 * ek * es);
@@ -94,7 +94,7 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     }
     p.add("x_in", L, r1 * D * 4);
     p.add("x_tmp", -1, r2 * D * 4);
-    p.add("conv_out", -1, (size_t)B * HW * 64 * es);
+    p.add("conv_out", -1, (size_t)B * HW * dc * es);
   } else {
     p.add("x_a", -1, r2 * D * 4);
     p.add("x_b", -1, r2 * D * 4);
@@ -108,9 +108,9 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
   p.add("vt", -1, 2 * (size_t)B * nh * 64 * npad * es);
   p.add("relh_s", -1, 2 * (size_t)B * nh * hp * npad * 4);  // forward: key-major relh scratch [stream][head][kh][token]
   p.add("taps", -1, r1 * nt * D * es);
-  p.add("feat", -1, (size_t)B * HW * 64 * es);
+  p.add("feat", -1, (size_t)B * HW * dc * es);
   if (train) {
-    p.add("feat2", -1, (size_t)B * HW * 64 * es);
+    p.add("feat2", -1, (size_t)B * HW * dc * es);
     p.add("dtaps", -1, r1 * nt * D * es);
     p.add("dx", -1, r1 * D * 4);
     p.add("dx_t", -1, r1 * D * es);
@@ -201,8 +201,21 @@ static int conv_row_split(int base_items, int steps_total) {
   }
   return best;
 }
-template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int B, int ty0, hipStream_t st) {
+template <typename T, int MODE, int DC> static void launch_conv_halo(const ConvArgs& a, int B, int ty0, hipStream_t st) {
+  typedef ConvGeo<DC> G;
+  constexpr int lds = G::HALO * 64 * sizeof(T);
+  static bool once = (allow_lds(conv3x3_kernel<T, MODE, DC>, lds), true);
+  (void)once;
+  ConvArgs b = a;
+  b.ty0 = ty0;
+  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, DC>), dim3(a.W / 32, (a.H - ty0 * CONV_TR) / G::TR, B), dim3(256), lds, st, b);
+}
+template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int dc, int B, int ty0, hipStream_t st) {
   static const bool ring_env = !getenv("BSG_CONV_NO_RING");
+  if (dc == 128) {  // BASELINE config 5: the 288 KB filter bank does not fit the ring kernel's LDS -> halo-tile kernel, two K passes
+    launch_conv_halo<T, MODE, 128>(a, B, ty0, st);
+    return;
+  }
   if constexpr (sizeof(T) == 2) {
     if (ring_env) {
       static bool once = (allow_lds(conv3x3_ring_kernel<T, MODE>, CR_LDS), true);
@@ -216,11 +229,7 @@ template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int B
       return;
     }
   }
-  static bool once2 = (allow_lds(conv3x3_kernel<T, MODE>, CONV_HALO * 64 * sizeof(T)), true);
-  (void)once2;
-  ConvArgs b = a;
-  b.ty0 = ty0;
-  hipLaunchKernelGGL((conv3x3_kernel<T, MODE>), dim3(a.W / 32, a.H / CONV_TR - ty0, B), dim3(256), CONV_HALO * 64 * sizeof(T), st, b);
+  launch_conv_halo<T, MODE, 64>(a, B, ty0, st);
 }
 
 // dK/dV launch: 16-bit dtypes stream 128-query tiles when the padded statistics rows hold the rounded-up length
@@ -271,7 +280,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
                                               const float* pmask, int emb, float* pred, void* ws, int train, int fe = 0) {
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, train), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
-  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps;
+  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, dc = m->c.decoder_hidden;
   const float scale = 0.125f;  // head_dim^-0.5, head_dim == 64
   T* patch_a = c.template at<T>("patch_a");
   T* ln_out = c.template at<T>("ln_out");
@@ -392,8 +401,9 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   }
   {
     GemmArgs g{};
-    g.A = taps; g.W = m->gw(6); g.M = B * N; g.N = 256 * 64; g.K = nt * D; g.lda = (long)nt * D;
+    g.A = taps; g.W = m->gw(6); g.M = B * N; g.N = 256 * dc; g.K = nt * D; g.lda = (long)nt * D;
     g.bias = (const float*)m->gw(8); g.out = feat; g.tokens = N; g.wp = wp; g.himg = m->c.canvas_h; g.wimg = m->c.canvas_w;
+    g.feat_lg = dc == 128 ? 7 : 6;
     gemm<T, A_PLAIN, EPI_FEAT>(m, g, st);
     CHECK_LAUNCH();
   }
@@ -402,8 +412,8 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     a.in = feat; a.w = m->gw(9); a.bias = (const float*)m->gw(11); a.out = train ? c.template at<T>("conv_out") : nullptr;
     a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
     a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
-    ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * 64 * 64);
-    launch_conv<T, CONV_FWD_FUSED>(a, B, 0, st);
+    ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * dc * dc);
+    launch_conv<T, CONV_FWD_FUSED>(a, dc, B, 0, st);
     CHECK_LAUNCH();
   }
   return 0;
@@ -413,7 +423,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
                                                int first_row = 0) {
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, 1), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
-  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, H = m->c.canvas_h, W = m->c.canvas_w;
+  const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, H = m->c.canvas_h, W = m->c.canvas_w, dc = m->c.decoder_hidden;
   const int rows = B * N;
   const float scale = 0.125f;
   constexpr bool kF32 = sizeof(T) == 4;
@@ -449,15 +459,20 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, (const unsigned*)amax, gscale, 8, (int*)(gscale + 16));
       CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL((head_bwd_kernel<T>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
-                       c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
-                       (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0, (const float*)gscale);
+    if (dc == 128)
+      hipLaunchKernelGGL((head_bwd_kernel<T, 128>), dim3((unsigned)((total * 8 + 255) / 256)), dim3(256), 0, st, dpred,
+                         c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
+                         (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0, (const float*)gscale);
+    else
+      hipLaunchKernelGGL((head_bwd_kernel<T, 64>), dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, st, dpred,
+                         c.template at<T>("conv_out"), (const float*)m->gw(12), (const float*)m->gw(13),
+                         (const float*)m->gw(14), dconv, B, H, W, m->c.layer_norm_eps, hb0, (const float*)gscale);
     CHECK_LAUNCH();
     ConvArgs a{};
     a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
     {
-      ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * CONV_TR) * W * 9 * 64 * 64);
-      launch_conv<T, CONV_PLAIN>(a, B, ty0, st);
+      ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * CONV_TR) * W * 9 * dc * dc);
+      launch_conv<T, CONV_PLAIN>(a, dc, B, ty0, st);
     }
     CHECK_LAUNCH();
     if (ph0 > 0) {  // token rows < ph0 receive exactly zero
@@ -465,7 +480,8 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         return fail("memset2d failed");
     }
     GemmArgs g{};
-    g.A = dfeat; g.W = m->gw(7); g.M = B * ntok; g.N = nt * D; g.K = 256 * 64; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
+    g.A = dfeat; g.W = m->gw(7); g.M = B * ntok; g.N = nt * D; g.K = 256 * dc; g.tokens = N; g.wp = wp; g.himg = H; g.wimg = W;
+    g.feat_lg = dc == 128 ? 7 : 6;
     g.a_rpg = ntok; g.t_off = ph0 * wp; g.o_rpg = ntok; g.o_gstride = N; g.o_off = ph0 * wp;
     g.out = dtaps; g.ldo = (long)nt * D;
     gemm<T, A_FEAT, EPI_PLAIN>(m, g, st);
@@ -590,7 +606,7 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   const bsg_config& c = *cfg;
   if (c.dtype != BSG_DTYPE_F32 && c.dtype != BSG_DTYPE_BF16 && c.dtype != BSG_DTYPE_F16) return fail("dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
   if (c.patch_size != 16) return fail("patch_size must be 16");
-  if (c.decoder_hidden != 64) return fail("decoder_hidden must be 64");
+  if (c.decoder_hidden != 64 && c.decoder_hidden != 128) return fail("decoder_hidden must be 64 or 128");
   if (c.num_heads <= 0 || c.hidden_size != c.num_heads * 64) return fail("head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_heads);
   if (c.hidden_size % 64 || c.mlp_dim % 64 || c.hidden_size > 2048) return fail("hidden_size / mlp_dim must be multiples of 64, hidden <= 2048");
   if (c.canvas_h % 32 || c.canvas_w % 32) return fail("canvas must be a multiple of 32 pixels in both axes");

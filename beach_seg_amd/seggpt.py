@@ -108,8 +108,9 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, 
     tab_i, tab_s = token_tables(sd, g)
     pw = sd["model.embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
     cw = sd["decoder.decoder_pred.conv.weight"].detach().to(device=device, dtype=torch.float32)  # [co][ci][ky][kx]
-    conv_w = cw.permute(0, 2, 3, 1).reshape(64, 9, 64)  # [co][tap][ci]
-    conv_wT = cw.flip(2, 3).permute(1, 2, 3, 0).reshape(64, 9, 64)  # [ci][tap'][co], taps flipped (dgrad)
+    dd = g.decoder_hidden_size
+    conv_w = cw.permute(0, 2, 3, 1).reshape(dd, 9, dd)  # [co][tap][ci]
+    conv_wT = cw.flip(2, 3).permute(1, 2, 3, 0).reshape(dd, 9, dd)  # [ci][tap'][co], taps flipped (dgrad)
     dw, dwT = lin("decoder.decoder_embed.weight")
     pw32 = pw.detach().to(device=device, dtype=torch.float32)
     patch = (_split3(pw32, dtype), _split3(pw32.t(), dtype)) if embed_split else (T(pw), T(pw.t()))
@@ -119,7 +120,7 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, 
         dw, dwT, f32(sd["decoder.decoder_embed.bias"]), T(conv_w), T(conv_wT),
         f32(sd["decoder.decoder_pred.conv.bias"]), f32(sd["decoder.decoder_pred.layernorm.weight"]),
         f32(sd["decoder.decoder_pred.layernorm.bias"]),
-        f32(sd["decoder.decoder_pred.head.weight"].reshape(3, 64)), f32(sd["decoder.decoder_pred.head.bias"]),
+        f32(sd["decoder.decoder_pred.head.weight"].reshape(3, dd)), f32(sd["decoder.decoder_pred.head.bias"]),
     ]
     assert len(table) == N.BSG_GLOBAL_WEIGHTS
     for i in range(g.num_hidden_layers):

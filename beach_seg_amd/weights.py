@@ -49,8 +49,8 @@ class SegGptGeometry:
         hp, wp = self.grid
         if self.head_dim != 64:
             raise ValueError(f"HIP attention kernels are built for head_dim 64, got {self.head_dim}")
-        if self.decoder_hidden_size != 64:
-            raise ValueError("HIP decoder kernels are built for decoder_hidden_size 64")
+        if self.decoder_hidden_size not in (64, 128):
+            raise ValueError("HIP decoder kernels are built for decoder_hidden_size 64 or 128")
         if self.patch_size != 16 or self.num_channels != 3:
             raise ValueError("patch_size must be 16 and num_channels 3")
         if hp % 2 or self.image_size[0] % 32:
@@ -83,6 +83,14 @@ class SegGptGeometry:
             mlp_dim=512, pretrain_image_size=224, merge_index=2,
             intermediate_hidden_state_indices=(2, 3, 4, 5),
         )
+
+    @staticmethod
+    def config5() -> "SegGptGeometry":
+        """BASELINE.json configs[4] ("4x512x512 tiles, deeper encoder (2x channels)") as SURVEY.md section 8(d) maps it onto
+        `SegGptConfig` (`HF:configuration_seggpt.py:57-75`): canvas 1024 x 512 (64 x 32 tokens), hidden 2048, 32 heads,
+        mlp 4 x hidden, decoder width 128, 24 layers.  Random-init only: no checkpoint of this shape exists."""
+        return SegGptGeometry(hidden_size=2048, num_attention_heads=32, image_size=(1024, 512), mlp_dim=8192,
+                              decoder_hidden_size=128)
 
     def to_hf_kwargs(self) -> dict:
         return dict(

@@ -32,8 +32,26 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-TRAIN_FLOPS_PER_TILE = 3.2681e12  # forward 1589.7 GF + minimum dgrad 1678.3 GF
+TRAIN_FLOPS_PER_TILE = 3.2681e12  # forward 1589.7 GF + minimum dgrad 1678.3 GF (ViT-L; = flops_per_tile)
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def flops_per_tile(g) -> tuple[float, float]:
+    """(forward, minimum dgrad) ALGORITHMIC flops of one tile for geometry `g`: SURVEY.md section 8(d)'s formula (2 x MAC;
+    ViT-L: 1589.7 GF / 1678.3 GF, reproducing torch's FlopCounterMode to 4 digits; config 5: 7.78 TF / 7.88 TF)."""
+    hp, wp = g.grid
+    N, D, L, m = hp * wp, g.hidden_size, g.num_hidden_layers, g.merge_index
+    nt, dd, (H, W) = len(g.intermediate_hidden_state_indices), g.decoder_hidden_size, g.image_size
+    patch = 2.0 * N * 768 * D                       # one canvas through Conv2d(3 -> D, k16, s16)
+    lin = 2.0 * N * D * (4 * D + 2 * g.mlp_dim)     # qkv + proj + fc1 + fc2 of one layer-stream
+    att_mm = 4.0 * N * N * D                        # QK^T + PV
+    rel = 2.0 * N * (hp + wp) * D                   # decomposed rel-pos einsums
+    dec = 2.0 * N * (nt * D) * (256 * dd)           # decoder_embed
+    conv = 2.0 * H * W * 9 * dd * dd
+    head = 2.0 * H * W * dd * 3
+    fwd = 2 * patch + (L + m + 1) * (lin + att_mm + rel) + dec + conv + head  # two streams up to the merge block
+    bwd = L * (lin + 2 * att_mm + rel) + dec + conv + head + patch / 2        # image stream only; prompt half of the embed dgrad
+    return fwd, bwd
 
 
 def cpu_model_name() -> str:
@@ -136,12 +154,15 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per GPU per step (default: 64; 32 for --geometry config5)")
     ap.add_argument("--prompts", type=int, default=64, help="number of learnable prompt images P")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--geometry", default="vit_large")
+    ap.add_argument("--geometry", default="vit_large", help="vit_large (BASELINE configs[1], the headline) | config5 (configs[4]: "
+                    "1024x512 canvas, hidden 2048, 32 heads, decoder 128) | tiny | small")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip fwd_ms_per_tile / f32 parity mode / profiled steps")
+    ap.add_argument("--no-predict", action="store_true", help="skip the predict_8192 extra (BASELINE configs[3] end to end, ~15 s)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config5 extra (BASELINE configs[4] geometry, ~20 s)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra profiled steps after the timed region")
     ap.add_argument("--loss-variant", default="reference", choices=["reference", "per_sample"])
     args = ap.parse_args()
@@ -171,6 +192,10 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     g = getattr(SegGptGeometry, args.geometry)()
+    if not args.batch:
+        args.batch = 32 if args.geometry == "config5" else 64
+    fwd_flops, bwd_flops = flops_per_tile(g)
+    train_flops = fwd_flops + bwd_flops
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     log(f"rank {rank}/{world}: building {args.geometry} ({args.dtype}) on {dev}")
     # BSG_BENCH_CPU_WEIGHTS: build the (bit-identical) synthetic weights on the host -- under rocprofv3 --pmc the
@@ -236,13 +261,13 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"SegGPT {args.geometry} 896x448 canvas, batch {B} tiles/GPU of 3x448x448 "
+            "config": {"workload": f"SegGPT {args.geometry} {g.image_size[0]}x{g.image_size[1]} canvas, batch {B} tiles/GPU of 3x{Hh}x{W} "
                                    f"(synthetic 4-band tile -> 3-ch), fwd + SegGptLoss({args.loss_variant}) + dgrad to "
                                    f"{P} prompt images + AdamW" + (", RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "prompts": P, "parallelism": f"dp{world}",
-                       "train_flops_per_tile": TRAIN_FLOPS_PER_TILE},
-            "whole_step_tflops_per_gpu": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12, 1),
-            "whole_step_frac_of_mfma_peak": round(tiles / world / dt * TRAIN_FLOPS_PER_TILE / 1e12 / peak, 4),
+                       "train_flops_per_tile": round(train_flops)},
+            "whole_step_tflops_per_gpu": round(tiles / world / dt * train_flops / 1e12, 1),
+            "whole_step_frac_of_mfma_peak": round(tiles / world / dt * train_flops / 1e12 / peak, 4),
         }
         if prof is not None:
             ms, fl, n = prof["gemm"]
@@ -271,9 +296,19 @@ def main() -> None:
             tf = (time.perf_counter() - tf0) / nrep
             out["fwd_ms_per_tile"] = round(tf * 1e3 / B, 4)
             out["fwd"] = {"batch": B, "ms_per_batch": round(tf * 1e3, 2), "tiles_per_s": round(B / tf, 1), "hipgraph": True,
-                          "tflops": round(B / tf * 1.5897, 1), "reps": nrep}
+                          "tflops": round(B / tf * fwd_flops / 1e12, 1), "reps": nrep}
             log(f"inference forward (hipGraph, B={B}): {tf * 1e3:.1f} ms = {tf * 1e3 / B:.3f} ms/tile")
             del graphed
+        if world == 1 and not args.no_extras and args.dtype == "bf16" and args.geometry == "vit_large" and not args.no_predict:
+            # ---- BASELINE configs[3] END TO END (bench_predict.py --size 8192): 5,476 windows of a synthetic 8192 x 8192 mosaic
+            #      through device front-end -> hipGraph forward -> palette arg-min -> nearest resize + votes -> arg-max
+            from bench_predict import run_predict
+            from beach_seg_amd.config import BeachSegConfig
+            from beach_seg_amd.model import PromptModel
+
+            pconf = BeachSegConfig(checkpoint="synthetic:vit_large", precision="bf16-true", crop_size=112, batch_size=B)
+            out["predict_8192"] = run_predict(PromptModel(pconf, model=model), size=8192, batch=B, crop=112)
+            log(f"predict 8192^2: {out['predict_8192']['seconds']} s = {out['predict_8192']['tiles_per_s']} tiles/s")
         if world == 1 and not args.no_extras and args.dtype == "bf16" and args.geometry == "vit_large":
             # ---- the same train step in the two dtypes that reach north_star's 1e-3 (tests/test_gpu_parity.py): IEEE-half
             #      MFMA (same rate as bf16, loss-scaled dgrad) and exact-f32 MFMA (bit-exact masks)
@@ -298,6 +333,45 @@ def main() -> None:
                 log(f"{key} mode: {tx * 1e3:.0f} ms/step at B={Bx} = {Bx / tx:.1f} tiles/s")
                 del ex, mx
                 torch.cuda.empty_cache()
+        if world == 1 and not args.no_extras and not args.no_config5 and args.dtype == "bf16" and args.geometry == "vit_large":
+            # ---- BASELINE configs[4] geometry on ONE GPU (the 8-GPU DDP form is the driver's to launch): 1024 x 512 canvas,
+            #      hidden 2048 / 32 heads / decoder 128, 24 layers, bf16 train step, with its own algorithmic-FLOP roofline
+            g5 = SegGptGeometry.config5()
+            f5, b5 = flops_per_tile(g5)
+            B5, h5, w5 = 32, g5.image_size[0] // 2, g5.image_size[1]
+            m5 = SegGptNative(synth_state_dict(g5, seed=0, device=wdev), g5, device=dev, dtype=torch.bfloat16)
+            e5 = PromptTrainEngine(m5, torch.rand(B5, 3, h5, w5, device=dev, generator=pgen), lr=1e-3, loss_variant=args.loss_variant)
+            x5 = [torch.randn(B5, 3, h5, w5, device=dev, generator=gen) for _ in range(3)]
+            yes5, idx5 = torch.ones(B5, 1, h5, w5, dtype=torch.bool, device=dev), torch.arange(B5, device=dev)
+            s5 = lambda: e5.step(x5[0], x5[1], yes5, idx5, x5[2])
+            s5()
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(3):
+                l5 = s5()
+            torch.cuda.synchronize()
+            t5 = (time.perf_counter() - t5) / 3
+            m5.profile(True)
+            s5()
+            torch.cuda.synchronize()
+            p5 = m5.profile_read()
+            m5.profile(False)
+            out["config5"] = {
+                "workload": f"SegGPT config5 (BASELINE configs[4] geometry: canvas {g5.image_size[0]}x{g5.image_size[1]}, hidden "
+                            f"{g5.hidden_size}, {g5.num_attention_heads} heads, mlp {g5.mlp_dim}, decoder {g5.decoder_hidden_size}, "
+                            f"{g5.num_hidden_layers} layers), batch {B5} tiles of 3x{h5}x{w5}, bf16 train step, 1 GPU",
+                "tiles_per_s": round(B5 / t5, 2), "ms_per_step": round(t5 * 1e3, 1), "steps": 3, "warmup": 1,
+                "train_flops_per_tile": round(f5 + b5), "whole_step_tflops": round(B5 / t5 * (f5 + b5) / 1e12, 1),
+                "whole_step_frac_of_mfma_peak": round(B5 / t5 * (f5 + b5) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "roofline": {"kernel": "gemm_nt_kernel (all epilogues)", "bound": "mfma",
+                             "achieved": round(p5["gemm"][1] / (p5["gemm"][0] * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(p5["gemm"][1] / (p5["gemm"][0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)},
+                "kernel_time_ms_per_step": {k: round(v[0], 2) for k, v in p5.items()},
+                "kernel_tflops": {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0 for k, v in p5.items()},
+                "loss_finite": bool(torch.isfinite(l5)), "workspace_GB": round(m5._lib.bsg_workspace_bytes(m5._h, B5, 1) / 1e9, 1)}
+            log(f"config5: {t5 * 1e3:.0f} ms/step at B={B5} = {B5 / t5:.1f} tiles/s")
+            del e5, m5, x5
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle (B=2, 1 warm-up + 3 timed steps) ...")
             out["cpu_baseline"] = cpu_baseline(g, host_threads())

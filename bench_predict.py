@@ -23,6 +23,62 @@ from beach_seg_amd.model import PromptModel
 from beach_seg_amd.predict import Accumulator, crops_are_disjoint, grid_crops
 
 
+def run_predict(pm: PromptModel, size: int = 8192, batch: int = 64, crop: int = 112, prompts: int = 32, use_graph: bool = True,
+                rank: int = 0, world: int = 1) -> dict:
+    """The whole config-4 pipeline on `pm` (a `PromptModel` on the HIP network); returns the result record.  Timed region:
+    palette draw + device front-end + forward + decode + votes + arg-max over every window of this rank."""
+    dev = pm.device
+    conf = pm.conf
+    g = torch.Generator(device=dev).manual_seed(11)
+    S = conf.inpt_size
+    pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, S, S, device=dev, generator=g),
+                                 "mask": torch.randint(0, 4, (S, S), device=dev, generator=g, dtype=torch.uint8),
+                                 "nodata": torch.zeros(S, S, dtype=torch.bool)} for i in range(prompts)])
+    mosaic = (torch.rand(size // 64, size // 64, 3, device=dev, generator=g).repeat_interleave(64, 0).repeat_interleave(64, 1) * 255).to(torch.uint8)
+    crops_all = grid_crops(size, size, crop)
+    n_all = crops_all.shape[0]
+    order = torch.arange(n_all)[rank::world]  # this rank's windows
+    crops = crops_all[order]
+    n = crops.shape[0]
+    graphed = pm.model.capture_forward(batch) if use_graph else None
+    acc = Accumulator((size, size), conf.classes, dev)
+    acc.initialize_current("d0")
+    # host data of the whole loop goes up once (per-batch uploads block the host behind the previous batch's forward)
+    crops_dev = crops.to(dev)
+    idx_dev = (order % prompts).to(dev)
+    sizes = [min(batch, n - s) for s in range(0, n, batch)]
+    disjoint = crops_are_disjoint(crops)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    palettes = pm.create_palettes(sizes, train=True)
+    with torch.no_grad():
+        for b, s in enumerate(range(0, n, batch)):
+            cb = crops_dev[s:s + batch]
+            img = ops.tile_frontend(mosaic, cb, crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
+            pal, pal_norm = palettes[b]
+            pb, pmasks = pm.prepare_prompt(idx_dev[s:s + batch], pal, train=False)
+            if graphed is not None and img.shape[0] == batch:
+                out = graphed(img, pb["image"], pmasks)
+            else:
+                out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
+            pred = pm.process_pred_masks(out, pal_norm)
+            acc.update("d0", cb if disjoint else crops[s:s + batch], pred.to(torch.uint8), crop, disjoint=disjoint)
+    if world > 1:
+        acc.reduce_votes()
+    result = acc.result()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    return {"config": f"predict sliding window {size}x{size}, crop {crop}, batch {batch}, hipGraph={use_graph}",
+            "n_gpus": world, "tiles": n_all, "seconds": round(dt, 3), "tiles_per_s": round(n_all / dt, 1),
+            "fwd_ms_per_tile": round(dt / n_all * 1e3, 3), "inference_tflops": round(n_all / dt * 1.5897, 1),
+            "classes_present": torch.unique(result).tolist()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=8192)
@@ -39,57 +95,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     conf = BeachSegConfig(checkpoint="synthetic:vit_large", precision="bf16-true", crop_size=a.crop, batch_size=a.batch)
     pm = PromptModel(conf, device=dev)
-    g = torch.Generator(device=dev).manual_seed(11)
-    S = conf.inpt_size
-    pm.create_trainable_params([{"crop_idx": i, "date": "d", "image": torch.rand(3, S, S, device=dev, generator=g),
-                                 "mask": torch.randint(0, 4, (S, S), device=dev, generator=g, dtype=torch.uint8),
-                                 "nodata": torch.zeros(S, S, dtype=torch.bool)} for i in range(a.prompts)])
-    mosaic = (torch.rand(a.size // 64, a.size // 64, 3, device=dev, generator=g).repeat_interleave(64, 0).repeat_interleave(64, 1) * 255).to(torch.uint8)
-    crops_all = grid_crops(a.size, a.size, a.crop)
-    n_all = crops_all.shape[0]
-    order = torch.arange(n_all)[rank::world]  # this rank's windows
-    crops = crops_all[order]
-    n = crops.shape[0]
-    graphed = None if a.no_graph else pm.model.capture_forward(a.batch)
-    acc = Accumulator((a.size, a.size), conf.classes, dev)
-    acc.initialize_current("d0")
-    # host data of the whole loop goes up once (per-batch uploads block the host behind the previous batch's forward)
-    crops_dev = crops.to(dev)
-    idx_dev = (order % a.prompts).to(dev)
-    sizes = [min(a.batch, n - s) for s in range(0, n, a.batch)]
-    disjoint = crops_are_disjoint(crops)
+    rec = run_predict(pm, a.size, a.batch, a.crop, a.prompts, not a.no_graph, rank, world)
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    palettes = pm.create_palettes(sizes, train=True)
-    with torch.no_grad():
-        for b, s in enumerate(range(0, n, a.batch)):
-            cb = crops_dev[s:s + a.batch]
-            img = ops.tile_frontend(mosaic, cb, a.crop, S)  # padded crop + PIL-BICUBIC + /255 + Normalize
-            pal, pal_norm = palettes[b]
-            pb, pmasks = pm.prepare_prompt(idx_dev[s:s + a.batch], pal, train=False)
-            if graphed is not None and img.shape[0] == a.batch:
-                out = graphed(img, pb["image"], pmasks)
-            else:
-                out = pm.model(pixel_values=img, prompt_pixel_values=pb["image"], prompt_masks=pmasks).pred_masks
-            pred = pm.process_pred_masks(out, pal_norm)
-            acc.update("d0", cb if disjoint else crops[s:s + a.batch], pred.to(torch.uint8), a.crop, disjoint=disjoint)
-    if world > 1:
-        acc.reduce_votes()
-    result = acc.result()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
         dist.barrier()
         dist.destroy_process_group()
         if rank:
             return
-    n = n_all
-    print(json.dumps({"config": f"predict sliding window {a.size}x{a.size}, crop {a.crop}, batch {a.batch}, hipGraph={not a.no_graph}",
-                      "n_gpus": world, "tiles": n, "seconds": round(dt, 3), "tiles_per_s": round(n / dt, 1), "fwd_ms_per_tile": round(dt / n * 1e3, 3),
-                      "inference_tflops": round(n / dt * 1.5897, 1), "classes_present": torch.unique(result).tolist()}))
+    print(json.dumps(rec))
 
 
 if __name__ == "__main__":

@@ -52,9 +52,10 @@ typedef struct bsg_model bsg_model;
 /* Weight table (device pointers, caller-owned, must outlive the handle).  "T" = activation dtype of the
  * config; "wT" = the same Linear weight transposed ([in][out]) for the dgrad GEMMs.
  * global: 0 patch_w T[D][768]   1 patch_wT T[768][D] (embed_split: see bsg_config)   2 tok_table_instance f32[2][N][D]
- *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*64][taps*D]
- *         7 dec_wT T[taps*D][256*64]   8 dec_b f32   9 conv_w T[64 co][9][64 ci]   10 conv_wT T[64 ci][9][64 co]
- *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][64]   15 head_b f32[3]
+ *         3 tok_table_semantic f32[2][N][D]   4 final_ln_g   5 final_ln_b   6 dec_w T[256*C][taps*D]
+ *         7 dec_wT T[taps*D][256*C]   8 dec_b f32   9 conv_w T[C co][9][C ci]   10 conv_wT T[C ci][9][C co]
+ *         (taps flipped)   11 conv_b   12 dec_ln_g   13 dec_ln_b   14 head_w f32[3][C]   15 head_b f32[3]
+ *         (C = decoder_hidden: 64, the reference checkpoint, or 128, BASELINE config 5)
  * layer l at 16 + 20*l: 0 ln1_g 1 ln1_b 2 qkv_w 3 qkv_wT 4 qkv_b 5 proj_w 6 proj_wT 7 proj_b 8 ln2_g 9 ln2_b
  *         10 fc1_w 11 fc1_wT 12 fc1_b 13 fc2_w 14 fc2_wT 15 fc2_b 16 rel_pos_h f32[2Hp-1][64] 17 rel_pos_w f32
  *         18 rel_cat T[LH + LW][64], LH = roundup16(2Hp), LW = roundup16(2Wp): rel_pos_h rows at 0, rel_pos_w rows

@@ -17,6 +17,7 @@ Usage:  python oracle/gen_golden.py [--skip-vitl]
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import sys
 import tempfile
 import types
@@ -34,6 +35,7 @@ from oracle.gen_inputs import synth_inputs  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 PEAK_GAIN = 8.0  # q / k / rel-pos gain of the peaked-attention fixture (oracle/gen_inputs.peaked_state_dict)
+VITL_PEAK_GAIN = 4.0  # the same for the 1024-wide net: logits scale with hidden_size * gain^2 (sigma = 0.02 weights)
 
 
 def import_reference():
@@ -112,7 +114,8 @@ def attention_peak_stats(m, g, pix, prm, prompt_masks) -> dict:
     return stats
 
 
-def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int, tag: str, full: bool, peaked: float = 0.0):
+def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int, tag: str, full: bool, peaked: float = 0.0,
+            every_layer: bool = False):
     if peaked:
         from oracle.gen_inputs import peaked_state_dict
         sd = peaked_state_dict(g, wseed, peaked)
@@ -165,6 +168,8 @@ def run_e2e(ref_model, ref_ml, g: SegGptGeometry, B: int, wseed: int, iseed: int
         print(tag, "max logit above row mean per layer", [round(v, 1) for v in st_["max_logit"]],
               "mean row-max prob", [round(v, 3) for v in st_["mean_rowmax_prob"]])
         assert max(st_["max_logit"]) > 20.0, "the peaked fixture must drive logits past 20"
+        if every_layer:
+            assert min(st_["max_logit"]) > 20.0, "every layer's row-max logit must clear its row mean by 20"
     np.savez_compressed(GOLD / f"{tag}.npz", **rec)
     print(tag, "loss", float(loss), "pred_l2", float(pred.norm()), "grad_l2", float(grad.norm()))
     return m, sd
@@ -258,13 +263,22 @@ def run_predict_glue(ref_predict):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-vitl", action="store_true")
-    ap.add_argument("--only", default="", help="generate one case only: small_peaked")
+    ap.add_argument("--only", default="", help="generate one case only: small_peaked | tiny_dec128 | vitl_peaked")
+    ap.add_argument("--gain", type=float, default=0.0, help="peak gain override (vitl_peaked)")
     args = ap.parse_args()
     GOLD.mkdir(parents=True, exist_ok=True)
     torch.set_num_threads(8)
     ref_model, ref_ml, ref_predict = import_reference()
     if args.only == "small_peaked":
         run_e2e(ref_model, ref_ml, SegGptGeometry.small(), B=2, wseed=2, iseed=6, tag="small_peaked_e2e", full=False, peaked=PEAK_GAIN)
+        return
+    if args.only == "tiny_dec128":  # decoder_hidden_size = 128 (BASELINE config 5's decoder width) through the HF module
+        run_e2e(ref_model, ref_ml, dataclasses.replace(SegGptGeometry.tiny(), decoder_hidden_size=128), B=2, wseed=4, iseed=8,
+                tag="tiny_dec128_e2e", full=True)
+        return
+    if args.only == "vitl_peaked":  # full ViT-L with PEAKED attention (what a trained checkpoint produces), 24 layers deep
+        run_e2e(ref_model, ref_ml, SegGptGeometry.vit_large(), B=1, wseed=0, iseed=7, tag="vitl_peaked_e2e", full=False,
+                peaked=args.gain or VITL_PEAK_GAIN, every_layer=True)
         return
     run_wrapper(ref_model, ref_ml)
     run_predict_glue(ref_predict)
@@ -274,6 +288,10 @@ def main():
     run_e2e(ref_model, ref_ml, SegGptGeometry.small(), B=2, wseed=2, iseed=6, tag="small_peaked_e2e", full=False, peaked=PEAK_GAIN)
     if not args.skip_vitl:
         run_e2e(ref_model, ref_ml, SegGptGeometry.vit_large(), B=1, wseed=0, iseed=7, tag="vitl_e2e", full=False)
+        run_e2e(ref_model, ref_ml, SegGptGeometry.vit_large(), B=1, wseed=0, iseed=7, tag="vitl_peaked_e2e", full=False,
+                peaked=VITL_PEAK_GAIN, every_layer=True)
+    run_e2e(ref_model, ref_ml, dataclasses.replace(SegGptGeometry.tiny(), decoder_hidden_size=128), B=2, wseed=4, iseed=8,
+            tag="tiny_dec128_e2e", full=True)
 
 
 if __name__ == "__main__":

@@ -43,15 +43,23 @@ def relmax(a, b):
 _models = {}
 
 
+def geometry_of(gname):
+    import dataclasses
+
+    if gname == "tiny_dec128":  # the tiny net with BASELINE config 5's decoder width
+        return dataclasses.replace(SegGptGeometry.tiny(), decoder_hidden_size=128)
+    return getattr(SegGptGeometry, gname)()
+
+
 def model_for(gname, wseed, dtype, peak_gain=0.0):
     from beach_seg_amd.seggpt import SegGptNative
 
     key = (gname, wseed, dtype, peak_gain)
     if key not in _models:
         _models.clear()  # one resident model at a time
-        g = getattr(SegGptGeometry, gname)()
+        g = geometry_of(gname)
         if peak_gain:
-            dev_sd = peaked_state_dict(g, wseed, peak_gain)
+            dev_sd = peaked_state_dict(g, wseed, peak_gain, device=DEV if gname == "vit_large" else "cpu")
         else:
             dev_sd = synth_state_dict(g, seed=wseed, device=DEV if gname == "vit_large" else "cpu")
         _models[key] = SegGptNative(dev_sd, g, device=DEV, dtype=dtype)
@@ -59,7 +67,7 @@ def model_for(gname, wseed, dtype, peak_gain=0.0):
 
 
 def run_case(gname, rec, B, dtype):
-    g = getattr(SegGptGeometry, gname)()
+    g = geometry_of(gname)
     model = model_for(gname, int(rec["wseed"]), dtype, float(rec["peak_gain"]) if "peak_gain" in rec.files else 0.0)
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, B, int(rec["iseed"]))
     pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
@@ -97,18 +105,28 @@ def check_masks_by_margin(pred_ref_bottom, pn, masks, ref_masks, delta, max_mism
 # f32: the north_star bar.  bf16: ~1.5 x the measured error of each geometry (see the module docstring), `mm` = allowed
 # number of differing mask pixels (of the pixels the fixture holds: all for tiny, every 8th row / column otherwise).
 TOL = {
-    torch.float32: {k: dict(t=1e-4, loss=1e-5, mm=0) for k in ("tiny", "small", "small_peaked", "vit_large")},
+    torch.float32: {**{k: dict(t=1e-4, loss=1e-5, mm=0) for k in ("tiny", "tiny_dec128", "small", "small_peaked", "vit_large")},
+                    # peaked ViT-L amplifies rounding ~1e3 x (see the 16-bit rows): two fp32 evaluation orders differ by 2.4e-5 / 9.1e-5
+                    "vit_large_peaked": dict(t=1e-4, tg=3e-4, loss=1e-5, mm=0)},
     torch.float16: {   # IEEE half operands: ~8x less round-off than bf16; bars set from the measured values below
         "tiny": dict(t=1.2e-3, loss=1e-5, mm=4),          # measured pred 5.2e-4 / grad 7.4e-4, 1 of 8192 mask pixels
         "small": dict(t=1.2e-3, loss=1e-5, mm=2),         # 4.8e-4 / 6.7e-4, 0 of 6272
         "small_peaked": dict(t=2.5e-3, loss=1e-5, mm=2),  # 6.5e-4 / 1.63e-3, 0
         "vit_large": dict(t=2e-3, loss=1e-5, mm=2),       # 1.19e-3 / 1.32e-3 (rms-relative 0.9e-3 / 1.0e-3), 0 of 3136
+        "tiny_dec128": dict(t=1.2e-3, tg=3.5e-3, loss=1e-5, mm=4),  # 6.8e-4 / 2.45e-3 (precision model of tools/rounding_budget.py: 5.0e-4 / 1.4e-3)
+        # PEAKED attention 24 layers deep: measured 9.4e-3 / 3.2e-2 -- ten to thirty times north_star's 1e-3.  The precision model
+        # (profiles/r3_rounding_budget_vit_large_peaked_f16.json) reproduces it (9.0e-3 / 3.1e-2) from operand rounding alone:
+        # weights 37 %, LayerNorm outputs 27 %, q / k 24 % of the variance, all amplified through softmax rows whose logits
+        # stand 28-43 above the row mean.  No 16-bit mode is inside the tolerance in this regime; float32 is (2.4e-5 / 9.1e-5).
+        "vit_large_peaked": dict(t=1.5e-2, tg=5e-2, loss=1e-4, mm=32),
     },
     torch.bfloat16: {
         "tiny": dict(t=8e-3, loss=1e-3, mm=24),          # measured pred 4.1e-3 / grad 5.0e-3, 9 of 8192 mask pixels
         "small": dict(t=1e-2, loss=1e-3, mm=8),          # 5.0e-3 / 6.4e-3, 1 of 6272
         "small_peaked": dict(t=1.7e-2, loss=1e-3, mm=8),  # 5.4e-3 / 1.13e-2, 0 of 6272
         "vit_large": dict(t=1.6e-2, loss=1e-3, mm=8),    # 7.8e-3 / 1.03e-2, 0 of 3136
+        "tiny_dec128": dict(t=8e-3, tg=1e-2, loss=1e-3, mm=24),          # 4.2e-3 / 6.7e-3, 0 of 8192
+        "vit_large_peaked": dict(t=1.1e-1, tg=4e-1, loss=1e-3, mm=128),  # measured 7.2e-2 / 2.6e-1 (!): see the float16 comment
     },
 }
 
@@ -116,14 +134,18 @@ TOL = {
 DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
+@pytest.mark.parametrize("gname", ["tiny", "tiny_dec128"])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_tiny_end_to_end_vs_reference_vectors(golden_dir, dtype):
-    rec = np.load(golden_dir / "tiny_e2e.npz")
-    pred, loss, grad, masks, pn = run_case("tiny", rec, 2, dtype)
-    tol = TOL[dtype]["tiny"]
+def test_tiny_end_to_end_vs_reference_vectors(golden_dir, dtype, gname):
+    """`tiny_dec128`: the same net with decoder_hidden_size = 128 (BASELINE config 5's decoder width: pixel-shuffle epilogue
+    with 128-channel pixels, 3x3 conv 128 -> 128 in two K passes, LayerNorm(128) + GELU + 1x1 head, their backward), against
+    the vector the HF module produced for that config (`HF:modeling_seggpt.py:525-579`)."""
+    rec = np.load(golden_dir / f"{gname}_e2e.npz")
+    pred, loss, grad, masks, pn = run_case(gname, rec, 2, dtype)
+    tol = TOL[dtype][gname]
     e_pred, e_grad = relmax(pred, rec["pred"]), relmax(grad, rec["grad"])
-    print(f"[measured] tiny {dtype}: pred {e_pred:.2e} grad {e_grad:.2e} loss {abs(loss - float(rec['loss'])) / abs(float(rec['loss'])):.1e}")
-    assert e_pred < tol["t"] and e_grad < tol["t"]
+    print(f"[measured] {gname} {dtype}: pred {e_pred:.2e} grad {e_grad:.2e} loss {abs(loss - float(rec['loss'])) / abs(float(rec['loss'])):.1e}")
+    assert e_pred < tol["t"] and e_grad < tol.get("tg", tol["t"])
     assert abs(loss - float(rec["loss"])) < tol["loss"] * abs(float(rec["loss"]))
     ref_masks = torch.from_numpy(rec["masks"]).long()
     if dtype == torch.float32:
@@ -136,7 +158,7 @@ def test_tiny_end_to_end_vs_reference_vectors(golden_dir, dtype):
 
 def _sliced_case(golden_dir, fixture, gname, B, dtype):
     rec = np.load(golden_dir / fixture)
-    key = "small_peaked" if "peaked" in fixture else gname
+    key = gname + "_peaked" if "peaked" in fixture else gname
     pred, loss, grad, masks, pn = run_case(gname, rec, B, dtype)
     tol, st = TOL[dtype][key], int(rec["stride"])
     e_pred, e_grad = relmax(pred[:, :, ::st, ::st], rec["pred_slice"]), relmax(grad[:, :, ::st, ::st], rec["grad_slice"])
@@ -144,9 +166,9 @@ def _sliced_case(golden_dir, fixture, gname, B, dtype):
     e_gl2 = abs(float(grad.double().norm()) - float(rec["grad_l2"])) / float(rec["grad_l2"])
     print(f"[measured] {key} {dtype}: pred {e_pred:.2e} grad {e_grad:.2e} |pred|2 {e_pl2:.1e} |grad|2 {e_gl2:.1e} "
           f"loss {abs(loss - float(rec['loss'])) / abs(float(rec['loss'])):.1e}")
-    assert e_pred < tol["t"] and e_grad < tol["t"]
+    assert e_pred < tol["t"] and e_grad < tol.get("tg", tol["t"])
     assert abs(loss - float(rec["loss"])) < tol["loss"] * abs(float(rec["loss"]))
-    assert e_pl2 < tol["t"] and e_gl2 < 2 * tol["t"]
+    assert e_pl2 < tol["t"] and e_gl2 < 2 * tol.get("tg", tol["t"])
     m8 = masks.numpy().astype(np.uint8)
     if dtype == torch.float32:
         assert np.array_equal(m8[:, ::st, ::st], rec["masks_slice"])
@@ -176,6 +198,14 @@ def test_small_peaked_attention_vs_reference_vectors(golden_dir, dtype):
 def test_vit_large_vs_reference_vectors(golden_dir, dtype):
     """Full reference geometry (ViT-L, 24 layers, 370.7 M parameters), B=1."""
     _sliced_case(golden_dir, "vitl_e2e.npz", "vit_large", 1, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vit_large_peaked_attention_vs_reference_vectors(golden_dir, dtype):
+    """ViT-L with PEAKED attention, 24 layers deep (q / k / rel-pos x 4: the row-max logit clears the row mean by 28-43 in
+    every layer, mean row-max probability ~0.5): the softmax regime of a trained checkpoint, which the sigma = 0.02 fixture
+    (near-uniform rows) does not reach.  Vector generated by the HF module (`HF:modeling_seggpt.py:313-348`)."""
+    _sliced_case(golden_dir, "vitl_peaked_e2e.npz", "vit_large", 1, dtype)
 
 
 def test_against_oracle_semantic_embedding_and_no_labels():
@@ -487,19 +517,19 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
         assert (got.cpu() == want).float().mean().item() > 0.99  # pred differs from HF's by ~1e-6: near-ties may flip
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
-    """BASELINE config 5 geometry class: 64 x 32 token grid (1024 x 512 canvas: no padded key slots, Hp = 64) and a
-    2048-wide encoder with 32 heads; 2 layers so the CPU oracle finishes in seconds.  No reference checkpoint of this
+    """BASELINE config 5 geometry (`SegGptGeometry.config5`): 64 x 32 token grid (1024 x 512 canvas: no padded key slots, Hp =
+    64), a 2048-wide encoder with 32 heads and the 128-channel decoder; 2 layers so the CPU oracle finishes in seconds.  No reference checkpoint of this
     shape exists, so parity is against the oracle (itself pinned on the reference geometry).  bf16 is the dtype
     config 5 names (Hp = 64 with no padded key slots in the transposing-read attention path)."""
     import dataclasses
 
     from beach_seg_amd.seggpt import SegGptNative
 
-    g = dataclasses.replace(SegGptGeometry.tiny(), hidden_size=2048, num_attention_heads=32, mlp_dim=4096,
-                            image_size=(1024, 512), pretrain_image_size=224, num_hidden_layers=2, merge_index=0,
+    g = dataclasses.replace(SegGptGeometry.config5(), mlp_dim=4096, num_hidden_layers=2, merge_index=0,
                             intermediate_hidden_state_indices=(0, 1))
+    assert (g.hidden_size, g.num_attention_heads, g.image_size, g.decoder_hidden_size) == (2048, 32, (1024, 512), 128)
     _models.clear()
     sd = synth_state_dict(g, seed=5)
     model = SegGptNative(sd, g, device=DEV, dtype=dtype)
@@ -515,7 +545,8 @@ def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
     out = model(pixel_values=pix.to(DEV), prompt_pixel_values=p, prompt_masks=pm.to(DEV))
     loss = ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference")
     loss.backward()
-    t, tl = (1e-4, 1e-5) if dtype == torch.float32 else (1.2e-2, 1e-3)  # bf16, 2 wide layers: measured 7.3e-3 / 7.3e-3
+    # bf16, 2 wide layers: measured 7.3e-3 / 7.3e-3 (decoder 64); f16 ~8x below
+    t, tl = {torch.float32: (1e-4, 1e-5), torch.bfloat16: (1.2e-2, 1e-3), torch.float16: (2e-3, 1e-5)}[dtype]
     print(f"[measured] config-5 class {dtype}: pred {relmax(out.pred_masks, pred_ref):.2e} grad {relmax(p.grad, grad_ref):.2e}")
     assert relmax(out.pred_masks, pred_ref) < t
     assert abs(loss.item() - loss_ref.item()) < tl * abs(loss_ref.item())
