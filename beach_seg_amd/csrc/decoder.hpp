@@ -372,6 +372,210 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ring_kernel(ConvRingArgs ra) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same walker with EIGHT waves in two groups that run in ANTI-PHASE (round 3).  In the four-wave kernel every SIMD
+// holds one wave, so the 288-MFMA phase of a step (MFMA pipe busy, vector ALU idle) and its fused bias + LayerNorm + GELU +
+// 1x1-head epilogue (vector ALU busy -- SQ_ACTIVE_INST_VALU 0.52 of the kernel -- MFMA pipe idle) run one after the other:
+// mfma_busy 0.26.  Here a wave owns ONE row of the 8-row step (2 x 4 accumulator tiles, 144 MFMAs); group 0 (waves 0-3,
+// rows 0-3) and group 1 (waves 4-7, rows 4-7) share the SIMDs pairwise and are held half a step apart by two barriers per
+// step: while one group is in its MFMA phase the other is in its epilogue, so the two pipes of a SIMD work at the same time:
+//   half-period 2k   : group 0 MFMA(step k)   | group 1 epilogue(step k-1)     [all waves: DMA of step k+1's 8 new rows]
+//   half-period 2k+1 : group 0 epilogue(k)    | group 1 MFMA(step k)
+// The ring is the four-wave kernel's (18 rows): the rows of step k+1 replace interior rows of step k-1, whose last reader
+// (group 1's MFMA phase, half-period 2k-1) is a barrier behind the issue (start of half-period 2k).  Filter bank, ring image,
+// swizzles, DMA pieces and the epilogue arithmetic are unchanged.
+template <typename T, int MODE>
+__global__ __launch_bounds__(512, 1) void conv3x3_ring8_kernel(ConvRingArgs ra) {
+  static_assert(sizeof(T) == 2, "ring kernel: 16-bit activations (128-byte pixels)");
+  typedef typename Traits<T>::Chunk Chunk;
+  const ConvArgs& a = ra.c;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;                 // filter bank, [64 co] rows of CR_WROW bytes: [tap][ci]
+  char* ring = smem + CR_W_BYTES;  // [CR_RING][CR_SLOT_PX] pixels x 128 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wrow = wave;  // group; row of the 8-row step this wave owns (group g: rows 4g .. 4g+3)
+  const int frow = lane & 15, fchunk = lane >> 4;
+
+  for (int i = tid; i < 64 * 72; i += 512) {
+    const int co = i / 72, ch = i % 72;
+    *(Chunk*)(wl + co * CR_WROW + ch * 16) = *(const Chunk*)((const char*)a.w + ((long)co * 72 + ch) * 16);
+  }
+
+  const int strips = a.W / 32, steps_total = (a.H - ra.y_begin) / CR_ROWS;
+  const int items = ra.batch * strips * ra.nsplit;
+  const char* zero = (const char*)bsg_conv_zero_page;
+  const int lp = lane >> 3, lq = lane & 7;
+  unsigned col_off[5];
+  bool col_ok[5];
+  auto issue_row = [&](const char* img, int row) {
+    const int slot = (row + CR_RING) % CR_RING;
+    const bool row_ok = row >= 0 && row < a.H;
+    const char* rp = img + (long)row * a.W * 128;
+#pragma unroll
+    for (int part = 0; part < 5; ++part) {
+      const char* src = (row_ok && col_ok[part]) ? rp + col_off[part] : zero + (lq << 4);
+      if (part < 4 || lane < 16) glds16(src, ring + (slot * CR_SLOT_PX + part * 8) * 128);
+    }
+  };
+
+  f32x4 cb[4], cg[4], cbe[4], cw0[4], cw1[4], cw2[4];
+  if (MODE == CONV_FWD_FUSED) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int c0 = ni * 16 + 4 * fchunk;
+      cb[ni] = *(const f32x4*)(a.bias + c0);
+      cg[ni] = *(const f32x4*)(a.ln_g + c0);
+      cbe[ni] = *(const f32x4*)(a.ln_b + c0);
+      cw0[ni] = *(const f32x4*)(a.head_w + c0);
+      cw1[ni] = *(const f32x4*)(a.head_w + 64 + c0);
+      cw2[ni] = *(const f32x4*)(a.head_w + 128 + c0);
+    }
+  }
+  const float hb0 = MODE == CONV_FWD_FUSED ? a.head_b[0] : 0.f, hb1 = MODE == CONV_FWD_FUSED ? a.head_b[1] : 0.f,
+              hb2 = MODE == CONV_FWD_FUSED ? a.head_b[2] : 0.f;
+  const unsigned wl_a = lds_addr(wl) + frow * CR_WROW + fchunk * 16, ring_a = lds_addr(ring);
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int part = item % ra.nsplit, t = item / ra.nsplit;
+    const int strip = t % strips, b = t / strips;
+    const int s0 = (int)((long)steps_total * part / ra.nsplit), s1 = (int)((long)steps_total * (part + 1) / ra.nsplit);
+    if (s1 <= s0) continue;
+    const int ns = s1 - s0, x0 = strip * 32;
+    const char* img = (const char*)a.in + (long)b * a.H * a.W * 128;
+#pragma unroll
+    for (int pt = 0; pt < 5; ++pt) {
+      const int p = pt * 8 + lp, x = x0 - 1 + p;
+      col_ok[pt] = x >= 0 && x < a.W;
+      col_off[pt] = (unsigned)(x * 128 + ((lq ^ (p & 7)) << 4));
+    }
+    __syncthreads();  // every wave is done with the ring of the previous item (and the filter bank is staged)
+    {  // rows y - 1 .. y + 8 of the first step: one per wave, the last two by waves 0 and 1
+      const int r0 = ra.y_begin + s0 * CR_ROWS - 1;
+      issue_row(img, r0 + wave);
+      if (wave < 2) issue_row(img, r0 + 8 + wave);
+    }
+    wait_vm0();
+    __syncthreads();
+
+    f32x4 acc[4][2];  // [ni][x half]: this wave's row of the step it last ran the MFMA phase of
+    for (int hp = 0; hp < 2 * ns + 1; ++hp) {
+      const bool even = !(hp & 1);
+      if (even && hp / 2 + 1 < ns)  // the next step's 8 new rows, one per wave
+        issue_row(img, ra.y_begin + (s0 + hp / 2) * CR_ROWS + CR_ROWS + 1 + wave);
+      const bool do_mma = grp == 0 ? (even && hp / 2 < ns) : !even;
+      const bool do_epi = grp == 0 ? !even : (even && hp >= 2);
+      const int st = s0 + (grp == 0 ? hp / 2 : (even ? hp / 2 - 1 : (hp - 1) / 2));
+      const int y0 = ra.y_begin + st * CR_ROWS;
+      if (do_mma) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int rbase[3];  // ring bases of the 3 input rows this wave touches: y0 + wrow - 1 + {0, 1, 2}
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rbase[i] = ((y0 + wrow - 1 + i + CR_RING) % CR_RING) * (CR_SLOT_PX * 128);
+        f32x4 fa[2][2], fw[2][4];
+        auto load_frags = [&](int it, f32x4 (&A)[2], f32x4 (&Wf)[4]) {
+          const int tap = it >> 1, ks = it & 1, dy = tap / 3, dx = tap - 3 * dy, c = fchunk + 4 * ks;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Wf[i] = lds_read16_nowait(wl_a + i * 16 * CR_WROW + tap * 128 + ks * 64);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int p = i * 16 + frow + dx;  // pixel inside the slot
+            A[i] = lds_read16_nowait(ring_a + rbase[dy] + p * 128 + ((c ^ (p & 7)) << 4));
+          }
+        };
+        load_frags(0, fa[0], fw[0]);
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+          if (it + 1 < 18) {
+            load_frags(it + 1, fa[(it + 1) & 1], fw[(it + 1) & 1]);
+            lds_wait<6>();  // iteration it's 6 fragments are in; the 6 just issued stay in flight under the MFMAs
+          } else {
+            lds_wait<0>();
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+              mma16(acc[ni][mi], __builtin_bit_cast(Chunk, fw[it & 1][ni]), __builtin_bit_cast(Chunk, fa[it & 1][mi]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (grp == 1) wait_vm0();  // group 1: its DMA piece (issued a half-period ago, behind it only old stores) has landed
+      }
+      if (do_epi) {
+        if (grp == 0) wait_vm0();  // group 0: its DMA piece of this step's start has landed; waited BEFORE the stores below
+        // acc[ni][mi][r]: pixel (y0 + wrow, x0 + mi * 16 + frow), channel ni*16 + 4*fchunk + r
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int y = y0 + wrow, x = x0 + mi * 16 + frow;
+          const long pix = ((long)b * a.H + y) * a.W + x;
+          f32x4 v[4];
+          float s = 0.f;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            v[ni] = acc[ni][mi];
+            if (MODE == CONV_FWD_FUSED) {
+              v[ni] += cb[ni];
+              s += v[ni][0] + v[ni][1] + v[ni][2] + v[ni][3];
+            }
+          }
+          if (MODE == CONV_PLAIN || a.out) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+              lo[ni] = pack2<T>(v[ni][0], v[ni][1]);
+              hi[ni] = pack2<T>(v[ni][2], v[ni][3]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const int ia = 2 * pr, ib = 2 * pr + 1;
+              auto r0 = __builtin_amdgcn_permlane16_swap(lo[ia], lo[ib], false, false);
+              auto r1 = __builtin_amdgcn_permlane16_swap(hi[ia], hi[ib], false, false);
+              const int ch = ((fchunk & 1) ? ib : ia) * 16 + (fchunk >> 1) * 8;
+              *(u32x4*)((T*)a.out + pix * 64 + ch) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+          }
+          if (MODE == CONV_FWD_FUSED) {
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            const float mean = s * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { v[ni][r] -= mean; q += v[ni][r] * v[ni][r]; }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            const float rstd = rsqrtf(q * (1.f / 64.f) + a.eps);
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float tt = gelu_f(v[ni][r] * rstd * cg[ni][r] + cbe[ni][r]);
+                o0 += tt * cw0[ni][r]; o1 += tt * cw1[ni][r]; o2 += tt * cw2[ni][r];
+              }
+            }
+            o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
+            o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
+            o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
+            if (fchunk == 0) {
+              const long hw = (long)a.H * a.W, base = (long)b * 3 * hw + (long)y * a.W + x;
+              a.pred[base] = o0 + hb0;
+              a.pred[base + hw] = o1 + hb1;
+              a.pred[base + 2 * hw] = o2 + hb2;
+            }
+          }
+        }
+      }
+      __syncthreads();  // the half-period boundary: roles swap; after an odd one the next step's rows are in for everybody
+    }
+  }
+}
+
 // Per-pixel backward of head (1x1) -> GELU -> LayerNorm(DC): dpred (fp32 NCHW) + saved conv output -> d conv out.
 // DC / 16 lanes per pixel (16 channels each, 32/64 contiguous bytes per lane), reductions by xor-shuffles inside the group.
 template <typename T, int DC>

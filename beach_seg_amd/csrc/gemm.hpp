@@ -59,11 +59,11 @@ struct GemmArgs {
 // 16-bit outputs, N % 16 == 0: exchange register pairs between the four 16-lane rows (v_permlane16_swap) so every
 // lane owns 8 consecutive columns -> 16-byte stores, 64 contiguous bytes per output row per instruction (the
 // narrow path writes 32-byte segments and doubles the number of memory requests of the tile's store burst).
-template <typename T, int EPI>
+template <typename T, int EPI, int NMI = 4>
 DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < NMI; ++mi) {
     const int m = mw + mi * 16 + frow;
     const bool mok = m < g.M;
     const int mc = mok ? m : g.M - 1;
@@ -115,17 +115,17 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
   }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int NMI = 4>
 DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
   if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
-      gemm_epilogue_wide16<T, EPI>(g, acc, mw, nw, frow, fchunk);
+      gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk);
       return;
     }
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < NMI; ++mi) {
     const int m = mw + mi * 16 + frow;
     if (m >= g.M) continue;
 #pragma unroll
@@ -394,8 +394,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
 #ifdef BSG_DIAG_STAMPS
 __device__ long long bsg_stamps[256 * 4];
 #endif
-template <typename T, int AMODE, int EPI>
+// TM = 224: the same kernel on 224-row tiles (wave rows of 112 = 64 + 48: the second accumulator half holds 3 instead of 4
+// row tiles, phases 2 / 3 run 12 MFMAs).  M = 64 x 1568 = 100,352 rows are 392 x 256 but 448 x 224, and 448 row tiles x
+// any number of column tiles is a multiple of 256 CUs / 4: every GEMM of the step becomes a whole number of rounds
+// (N = 1024: 1,568 tiles = 6.125 rounds -> 1,792 tiles = 7 rounds of 0.875; no thin last round, no 128^2 tail launch).
+template <typename T, int AMODE, int EPI, int TM = 256>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
+  static_assert(TM == 256 || TM == 224, "row tile: 256 or 224");
+  constexpr int WR = TM / 2;                 // rows per wave row: mh0 = 64, mh1 = WR - 64
+  constexpr int MH1 = (WR - 64) / 16;        // 16-row tiles of the second half: 4 or 3
+  constexpr int G1 = (WR - 64) / 8;          // 8-row DMA groups of the second half per wave row: 8 or 6
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BK = 8 * EPC;
   constexpr int BUF = 65536;  // A 256 x 128 B, then W 256 x 128 B
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (g.N + 255) >> 8, tiles_m = (g.M + 255) >> 8;
+  const int tiles_n = (g.N + 255) >> 8, tiles_m = (g.M + TM - 1) / TM;
   const int nwg = tiles_m * tiles_n;
   // Persistent form (g.persist): the grid is one workgroup per CU and each walks the virtual block ids
   // blockIdx.x, blockIdx.x + gridDim.x, ... in the order the dispatcher would have started them; the first K tile of
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
   const int gm = min(GM, tiles_m - grp * GM);
   const int tm = grp * GM + rem % gm, tn = rem / gm;
-  const int m0 = tm << 8, n0 = tn << 8;
+  const int m0 = tm * TM, n0 = tn << 8;
   const int wm = wave >> 2, wn = wave & 3;
 
   // ---- DMA sources: quarter q, instruction j = 2*wave + i (i = 0, 1) covers 8 rows
@@ -438,8 +446,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     for (int i = 0; i < 2; ++i) {
       const int j = 2 * wave + i;
       int row;  // row inside the 256-row A (q = 0, 3) or W (q = 1, 2) tile
-      if (q == 0) row = (j >> 3) * 128 + (j & 7) * 8;            // A, mh0: rows wm'*128 + [0, 64)
-      else if (q == 3) row = (j >> 3) * 128 + 64 + (j & 7) * 8;  // A, mh1
+      if (q == 0) row = (j >> 3) * WR + (j & 7) * 8;             // A, mh0: rows wm'*WR + [0, 64)
+      else if (q == 3) row = (j >> 3) * WR + 64 + min(j & 7, G1 - 1) * 8;  // A, mh1 (TM = 224: groups 6, 7 repeat group 5 --
+                                                                           // every wave keeps 2 DMA per quarter for vmcnt)
       else if (q == 1) row = (j >> 2) * 64 + (j & 3) * 8;        // W, nh0: rows wn'*64 + [0, 32)
       else row = (j >> 2) * 64 + 32 + (j & 3) * 8;               // W, nh1
       const int r = row + prow;
@@ -505,7 +514,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int r = wm * 128 + mh * 64 + i * 16 + frow, c = fchunk + 4 * ks;
+        if (mh && i >= MH1) continue;
+        const int r = wm * WR + mh * 64 + i * 16 + frow, c = fchunk + 4 * ks;
         af[ks][i] = *(const Chunk*)(la + r * 128 + ((c ^ (r & 7)) << 4));
       }
   };
@@ -525,7 +535,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mma16(acc[mh][nh * 2 + j][i], bf[nh][ks][j], af[ks][i]);
+        for (int i = 0; i < 4; ++i)
+          if (!mh || i < MH1) mma16(acc[mh][nh * 2 + j][i], bf[nh][ks][j], af[ks][i]);
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -560,15 +571,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
     // through a second copy of the address set-up (the epilogue below still needs this tile's m0 / n0 only)
     const int nb = xcd_remap(vb + gridDim.x, nwg);
     const int ngrp = nb / gsz, nrem = nb - ngrp * gsz, ngm = min(GM, tiles_m - ngrp * GM);
-    const int nm0 = (ngrp * GM + nrem % ngm) << 8, nn0 = (nrem / ngm) << 8;
+    const int nm0 = (ngrp * GM + nrem % ngm) * TM, nn0 = (nrem / ngm) << 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int j = 2 * wave + i;
         int row;
-        if (q == 0) row = (j >> 3) * 128 + (j & 7) * 8;
-        else if (q == 3) row = (j >> 3) * 128 + 64 + (j & 7) * 8;
+        if (q == 0) row = (j >> 3) * WR + (j & 7) * 8;
+        else if (q == 3) row = (j >> 3) * WR + 64 + min(j & 7, G1 - 1) * 8;
         else if (q == 1) row = (j >> 2) * 64 + (j & 3) * 8;
         else row = (j >> 2) * 64 + 32 + (j & 3) * 8;
         const int r = row + prow;
@@ -596,8 +607,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
       }
     primed = true;
   }
-  gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * 128, n0 + wn * 64, frow, fchunk);
-  gemm_epilogue<T, EPI>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, frow, fchunk);
+  gemm_epilogue<T, EPI>(g, acc[0], m0 + wm * WR, n0 + wn * 64, frow, fchunk);
+  gemm_epilogue<T, EPI, MH1>(g, acc[1], m0 + wm * WR + 64, n0 + wn * 64, frow, fchunk);
 #ifdef BSG_DIAG_STAMPS
   {
     const long long st_issued = __builtin_amdgcn_s_memtime();
@@ -796,6 +807,31 @@ template <int AMODE> static inline bool gemm_v4_ok(const GemmArgs& g, size_t es)
 
 #endif  // BSG_GEMM_V4
 
+// the 224-row form is instantiated for the 16-bit GEMMs of the encoder blocks only (plain rows; the decoder GEMMs are whole
+// rounds on 256-row tiles already)
+// 224-row tiles when they turn a ragged number of rounds (of 256 workgroups) into a cheaper whole one: cost = rounds x rows.
+// MEASURED (round 3, one box, TFLOP/s 256-row with the 128^2 tail launch vs 224-row): M 100,352 x N 1024 x K 1024 813 vs 806,
+// K 4096 1157 vs 1121, K 3072 1186 vs 1146; N 3072 x K 1024 1088 vs 1023; N 4096 1101 vs 1044; whole step 283.3 vs 288.9 ms.
+// 12.5 % fewer MFMAs per K tile shorten the K tile by ~3 % only -- the loop's period is set by the partner wave's load
+// segment (LDS-DMA issue + fragment reads + two barriers per phase), not by the MFMA cluster -- so 7 rounds of "0.875"
+// tiles cost 7 x 0.97 against 6 + the tail's ~0.6.  Kept behind -DBSG_GEMM_TM224 as an experiment.
+static inline bool gemm_pick_224(const GemmArgs& g) {
+  static const int tm_env = getenv("BSG_GEMM_TM") ? atoi(getenv("BSG_GEMM_TM")) : 0;  // 256 / 224 force (A/B runs)
+  if (tm_env) return tm_env == 224;
+  if (g.N <= 192) return false;
+  const long tn = (g.N + 255) / 256, tiles = (long)((g.M + 255) / 256) * tn, tiles224 = (long)((g.M + 223) / 224) * tn;
+  const long r256 = (tiles + 255) / 256, r224 = (tiles224 + 255) / 256;
+  return tiles > 256 && tiles % 256 != 0 && r224 * 224 < r256 * 256;
+}
+template <typename T, int AMODE, int EPI> constexpr bool gemm_tm224_built() {
+#ifdef BSG_GEMM_TM224  // experiment build only: measured SLOWER than the 256-row tiles
+  return sizeof(T) == 2 && AMODE == A_PLAIN &&
+         (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_PLAIN || EPI == EPI_GELU_BWD);
+#else
+  return false;
+#endif
+}
+
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 3;
@@ -813,8 +849,17 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
     }
 #endif
   } else {
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    const int tn = (g.N + 255) / 256;
+    const int tiles = ((g.M + 255) / 256) * tn;
     static const int persist = getenv("BSG_GEMM_PERSIST") ? atoi(getenv("BSG_GEMM_PERSIST")) : 256;  // workgroups in the persistent grid = CUs (0 = one workgroup per tile); 512: slower
+    if constexpr (gemm_tm224_built<T, AMODE, EPI>()) {
+      if (gemm_pick_224(g)) {
+        const long tiles224 = (long)((g.M + 223) / 224) * tn;
+        const int grid = persist > 0 ? (int)std::min<long>(tiles224, persist) : (int)tiles224;
+        hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI, 224>), dim3(grid), dim3(512), 131072, st, g);
+        return;
+      }
+    }
     const int grid = persist > 0 ? std::min(tiles, persist) : tiles;
     hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(grid), dim3(512), 131072, st, g);
   }

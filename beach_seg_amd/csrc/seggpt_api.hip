@@ -149,6 +149,10 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
+  if constexpr (gemm_tm224_built<T, AM, EPI>()) {
+    static bool once224 = (allow_lds(gemm_nt_kernel_v3<T, AM, EPI, 224>, 131072), true);
+    (void)once224;
+  }
 #ifdef BSG_GEMM_V4
   if constexpr (sizeof(T) == 2 && AM == A_PLAIN) {
     static bool once4 = (allow_lds(gemm_nt_kernel_v4<T, EPI>, 131072), true);
@@ -167,7 +171,9 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
   static const bool split_tail = !getenv("BSG_GEMM_NO_TAIL_SPLIT");
   constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
-  if (split_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
+  bool tm224 = false;
+  if constexpr (gemm_tm224_built<T, AM, EPI>()) tm224 = plain_rows && gemm_pick_224(g);
+  if (!tm224 && split_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
     const long tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
     const long full = tiles / 256, rem = tiles % 256;
     const long tm_main = (full * 256) / tn;  // row tiles that fit in the full rounds
@@ -218,14 +224,20 @@ template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int d
   }
   if constexpr (sizeof(T) == 2) {
     if (ring_env) {
-      static bool once = (allow_lds(conv3x3_ring_kernel<T, MODE>, CR_LDS), true);
+      static bool once = (allow_lds(conv3x3_ring_kernel<T, MODE>, CR_LDS), allow_lds(conv3x3_ring8_kernel<T, MODE>, CR_LDS), true);
       (void)once;
+      // BSG_CONV_RING8: 0 = the four-wave walker for both modes, 1 = the anti-phase eight-wave walker for the fused forward
+      // only, 2 (default) = for the dgrad as well (A/B runs)
+      static const int ring8 = getenv("BSG_CONV_RING8") ? atoi(getenv("BSG_CONV_RING8")) : 2;
       ConvRingArgs r{};
       r.c = a; r.y_begin = ty0 * CONV_TR; r.batch = B;
       const int strips = a.W / 32, steps_total = (a.H - r.y_begin) / CR_ROWS;
       r.nsplit = conv_row_split(B * strips, steps_total);
       const int items = B * strips * r.nsplit;
-      hipLaunchKernelGGL((conv3x3_ring_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(256), CR_LDS, st, r);
+      if (ring8 >= (MODE == CONV_FWD_FUSED ? 1 : 2))
+        hipLaunchKernelGGL((conv3x3_ring8_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(512), CR_LDS, st, r);
+      else
+        hipLaunchKernelGGL((conv3x3_ring_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(256), CR_LDS, st, r);
       return;
     }
   }

@@ -15,9 +15,12 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 192, 128), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 192, 128), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256),
+                                   (16 * 1568, 1024, 256), (25000, 1024, 192), (16 * 1568, 768, 128)])
 def test_gemm_nt_vs_torch(dtype, M, N, K):
-    """Every GEMM variant: v3 (256 x 256 persistent), v2 (N <= 192), ragged M / N edges, bias epilogue."""
+    """Every GEMM variant: v3 (256 x 256 persistent), v2 (N <= 192), ragged M / N edges, bias epilogue; the last three shapes
+    have a ragged second round of 256-row tiles (392 / 391 / 294 tiles), a ragged last row tile and a ragged last column tile
+    (they take the 224-row-tile form of v3 in the -DBSG_GEMM_TM224 experiment build)."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(dtype)
     w = (torch.rand(N, K, device=DEV, generator=g) * 2 - 1).to(dtype)
