@@ -31,7 +31,7 @@ class BsgConfig(C.Structure):
         ("canvas_h", C.c_int), ("canvas_w", C.c_int), ("patch_size", C.c_int), ("mlp_dim", C.c_int),
         ("decoder_hidden", C.c_int), ("merge_index", C.c_int), ("num_taps", C.c_int),
         ("taps", C.c_int * BSG_MAX_TAPS), ("layer_norm_eps", C.c_float), ("dtype", C.c_int),
-        ("embed_split", C.c_int),
+        ("embed_split", C.c_int), ("gemm_x3", C.c_int),
     ]
 
 

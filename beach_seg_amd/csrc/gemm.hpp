@@ -51,6 +51,9 @@ struct GemmArgs {
   int o_rpg;
   long o_gstride, o_off;
   const float* out_scale;  // EPI_UNPATCH: device scalar multiplied into the output (un-scaling of the fp16 gradient), or nullptr
+  int x3;                  // f32 only: 1 = the three-term f16 split form of v3 (gemm_nt_kernel_v3<..., X3 = true>)
+  float acc_scale;         // f32 only, 0 = off: the accumulator is multiplied by this power of two before the epilogue (x3 mode:
+                           // the Linear weights are stored multiplied by its inverse so that their f16 hi / lo parts are normal)
   int group_m;  // v3: row tiles per L2 group (0 = 4)
   int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
@@ -134,6 +137,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       if (n >= g.N) continue;
       f32x4 v = acc[ni][mi];
       if (EPI == EPI_NONE) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
+      if constexpr (sizeof(T) == 4) { if (g.acc_scale != 0.f) v *= g.acc_scale; }
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
         const f32x4 b = *(const f32x4*)(g.bias + n);
         v += b;
@@ -398,9 +402,17 @@ __device__ long long bsg_stamps[256 * 4];
 // row tiles, phases 2 / 3 run 12 MFMAs).  M = 64 x 1568 = 100,352 rows are 392 x 256 but 448 x 224, and 448 row tiles x
 // any number of column tiles is a multiple of 256 CUs / 4: every GEMM of the step becomes a whole number of rounds
 // (N = 1024: 1,568 tiles = 6.125 rounds -> 1,792 tiles = 7 rounds of 0.875; no thin last round, no 128^2 tail launch).
-template <typename T, int AMODE, int EPI, int TM = 256>
+// X3 (T = float only): "float32 at three f16 MFMAs".  Every f32 operand is used as hi = f16(x), lo = f16(x - hi) (22
+// significant bits; the products hi*hi + hi*lo + lo*hi are exact in the fp32 accumulator, lo*lo ~2^-22 is dropped): the
+// eight exact-f32 `v_mfma_f32_16x16x4_f32` of a K tile and accumulator tile (32 k-values, 8 x 32 cycles) become three
+// `v_mfma_f32_16x16x32_f16` (3 x 16 cycles) on the same fragment geometry (lane = row, 4 + 4 k-values per lane).  LDS image,
+// DMA, phases and epilogues are the f32 kernel's; activation fragments are split in registers once, at the head of the MFMA
+// phase that first uses them; weights come pre-split from the host (first version: both split in registers with the K = 16
+// f16 MFMA, which runs at half the rate on gfx950: 246 TFLOP/s against 117 for the exact kernel).
+template <typename T, int AMODE, int EPI, int TM = 256, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   static_assert(TM == 256 || TM == 224, "row tile: 256 or 224");
+  static_assert(!X3 || sizeof(T) == 4, "the three-term f16 split is the float32 kernel's option");
   constexpr int WR = TM / 2;                 // rows per wave row: mh0 = 64, mh1 = WR - 64
   constexpr int MH1 = (WR - 64) / 16;        // 16-row tiles of the second half: 4 or 3
   constexpr int G1 = (WR - 64) / 8;          // 8-row DMA groups of the second half per wave row: 8 or 6
@@ -528,15 +540,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
         bf[nh][ks][j] = *(const Chunk*)(lw + r * 128 + ((c ^ (r & 7)) << 4));
       }
   };
-  auto mfma_quadrant = [&](int mh, int nh) {
+  // X3: hi / lo halves of the ACTIVATION fragments, both k-steps of the K tile side by side (8 k-values per lane = one
+  // `v_mfma_f32_16x16x32_f16` operand; same register count as the f32 chunks they replace).  The WEIGHT operand arrives
+  // pre-split from the host: each 16-byte chunk of a weight row holds [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] of its four values
+  // (same bytes as four floats), so a W fragment needs no conversion at all.
+  f16x8 ah8[4], al8[4];
+  auto split_a = [&](int i) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = af[ks][i][e];
+          const f16_t hi = (f16_t)x;
+          ah8[i][4 * ks + e] = hi;
+          al8[i][4 * ks + e] = (f16_t)(x - (float)hi);
+        }
+    }
+  };
+  auto mfma_quadrant = [&](int mh, int nh, int p) {
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
+    if constexpr (X3) {  // convert the A fragments this phase's read step fetched: p0 a(mh0), p2 a(mh1)
+      if (p == 0 || p == 2)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (!mh || i < MH1) mma16(acc[mh][nh * 2 + j][i], bf[nh][ks][j], af[ks][i]);
+          if (!mh || i < MH1) split_a(i);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f16x8 w0 = __builtin_bit_cast(f16x8, bf[nh][0][j]), w1 = __builtin_bit_cast(f16x8, bf[nh][1][j]);
+        const f16x8 wh = f16x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        const f16x8 wl = f16x8{w0[4], w0[5], w0[6], w0[7], w1[4], w1[5], w1[6], w1[7]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!mh || i < MH1) {
+            f32x4& c = acc[mh][nh * 2 + j][i];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah8[i], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al8[i], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah8[i], c, 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (!mh || i < MH1) mma16(acc[mh][nh * 2 + j][i], bf[nh][ks][j], af[ks][i]);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -557,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       asm volatile("s_barrier" ::: "memory");
-      mfma_quadrant(p >> 1, (p == 1 || p == 2) ? 1 : 0);
+      mfma_quadrant(p >> 1, (p == 1 || p == 2) ? 1 : 0, p);
       asm volatile("s_barrier" ::: "memory");
     }
   }
@@ -838,7 +889,7 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   if (ver == 1) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
-  } else if (ver == 2 || g.N <= 192) {
+  } else if ((ver == 2 || g.N <= 192) && !(sizeof(T) == 4 && g.x3)) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
 #ifdef BSG_GEMM_V4
@@ -861,6 +912,12 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
       }
     }
     const int grid = persist > 0 ? std::min(tiles, persist) : tiles;
+    if constexpr (sizeof(T) == 4) {
+      if (g.x3) {
+        hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI, 256, true>), dim3(grid), dim3(512), 131072, st, g);
+        return;
+      }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(grid), dim3(512), 131072, st, g);
   }
 }

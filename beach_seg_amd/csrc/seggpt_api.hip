@@ -165,6 +165,9 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   g.stagger = stagger;
   static const int group_m = getenv("BSG_GEMM_GROUP_M") ? atoi(getenv("BSG_GEMM_GROUP_M")) : 0;
   g.group_m = group_m;
+  if constexpr (sizeof(T) == 4) {
+    if (m->c.gemm_x3) { g.x3 = 1; g.acc_scale = 1.0f / 32.0f; }  // Linear weights are stored x 2^5 in this mode (header)
+  }
   ProfScope ps(m, st, PC_GEMM, 2.0 * g.M * g.N * g.K);
   // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
@@ -173,6 +176,9 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
   bool tm224 = false;
   if constexpr (gemm_tm224_built<T, AM, EPI>()) tm224 = plain_rows && gemm_pick_224(g);
+  if constexpr (sizeof(T) == 4) {
+    if (g.x3) tm224 = true;  // x3: pre-split weights are readable by the 256 x 256 kernel only -> no 128^2 tail launch
+  }
   if (!tm224 && split_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
     const long tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
     const long full = tiles / 256, rem = tiles % 256;
@@ -455,7 +461,8 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   float* delta = c.template at<float>("delta");
   float* relhT = c.template at<float>("relhT");
   float* relwT = c.template at<float>("relwT");
-  float* gscale = std::is_same<T, f16_t>::value ? c.template at<float>("gscale") : nullptr;
+  // f16, and f32 with x3 GEMMs (f16 hi / lo operand halves): the dgrad chain runs on S * gradient
+  float* gscale = (std::is_same<T, f16_t>::value || (std::is_same<T, float>::value && m->c.gemm_x3)) ? c.template at<float>("gscale") : nullptr;
 
   {
     // grad_pred is zero on canvas rows < first_row (the reference loss only covers the bottom half, src/model.py:53-57):
@@ -630,6 +637,8 @@ int bsg_create(const bsg_config* cfg, const void* const* weights, int n_weights,
   if (c.merge_index < 0 || c.merge_index >= c.num_layers) return fail("merge_index out of range");
   if (c.embed_split != 0 && c.embed_split != 1) return fail("embed_split must be 0 or 1");
   if (c.embed_split && c.dtype == BSG_DTYPE_F32) return fail("embed_split applies to the 16-bit dtypes only");
+  if (c.gemm_x3 != 0 && c.gemm_x3 != 1) return fail("gemm_x3 must be 0 or 1");
+  if (c.gemm_x3 && c.dtype != BSG_DTYPE_F32) return fail("gemm_x3 applies to BSG_DTYPE_F32 only");
   const int need = BSG_GLOBAL_WEIGHTS + BSG_LAYER_WEIGHTS * c.num_layers;
   if (n_weights != need) return fail("weight table has %d entries, expected %d", n_weights, need);
   for (int i = 0; i < need; ++i) if (!weights[i]) return fail("weight table entry %d is null", i);

@@ -124,7 +124,7 @@ class PromptTrainEngine:
         gpix = m._run_backward(gpred, B, first_row=pred.shape[2] // 2)  # the loss gradient is zero on the prompt half
         ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
         self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
-        if m.dtype == torch.float16:  # device-side overflow guard of the half-precision dgrad chain (no host sync)
+        if m.dtype == torch.float16 or getattr(m, "gemm_x3", False):  # device-side overflow guard of the scaled dgrad chain (no host sync)
             self._overflow_f.copy_(m.grad_overflow_state(B)[:1])
         reduce_prompt_grads(self._flat, self.pg)  # RCCL over xGMI when world > 1
         ok = self._overflow_f == 0  # an overflow on ANY rank drops the step on every rank: replicas stay identical

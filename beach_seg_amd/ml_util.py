@@ -39,11 +39,13 @@ def geometry_of(checkpoint: str) -> SegGptGeometry:
     return SegGptGeometry.vit_large()
 
 
-def load_model(checkpoint: str, device="cuda:0", dtype=torch.bfloat16, geometry: SegGptGeometry | None = None) -> SegGptNative:
+def load_model(checkpoint: str, device="cuda:0", dtype=torch.bfloat16, geometry: SegGptGeometry | None = None,
+               gemm_x3: bool = False) -> SegGptNative:
     """`src/util/ml_util.py:7-13`: build the net, freeze it, eval mode.  (The reference's `torch.compile` has no
-    counterpart: the kernels are already fused.)"""
+    counterpart: the kernels are already fused.)  `gemm_x3` (float32 only): the Linear GEMMs as three f16 MFMAs on 22-bit
+    operand splits instead of exact-f32 MFMAs (`SegGptNative`)."""
     g = geometry or geometry_of(checkpoint)
-    return SegGptNative(load_state_dict(checkpoint, g, device), g, device=device, dtype=dtype).eval()
+    return SegGptNative(load_state_dict(checkpoint, g, device), g, device=device, dtype=dtype, gemm_x3=gemm_x3).eval()
 
 
 def build_palette(num_labels: int) -> list[tuple[int, int, int]]:

@@ -107,7 +107,9 @@ class PromptModel(torch.nn.Module):
         # Lightning precision strings (src/config.py:35): "32-true" -> exact-f32 kernels, "bf16-*" -> bf16, "16-*" -> IEEE half
         dtype = (torch.float32 if conf.precision.startswith("32") else
                  torch.float16 if conf.precision.startswith("16") else torch.bfloat16)
-        self.model = model if model is not None else ml_util.load_model(conf.checkpoint, device=device, dtype=dtype)
+        # "32-x3": float32 storage / attention / LayerNorm with the Linear GEMMs as three f16 MFMAs (22-bit operands)
+        self.model = model if model is not None else ml_util.load_model(conf.checkpoint, device=device, dtype=dtype,
+                                                                        gemm_x3="x3" in conf.precision)
         self.train_metrics = MulticlassF1(self.num_classes, self.nodata_idx, self.model.device)
         self.val_metrics = MulticlassF1(self.num_classes, self.nodata_idx, self.model.device)
         self.g = torch.Generator(device="cpu")  # src/model.py:98-99 (the draw itself is tiny; kept on the host)

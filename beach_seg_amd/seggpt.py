@@ -85,7 +85,11 @@ def _split3(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
-def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, embed_split: bool = False) -> list[torch.Tensor]:
+X3_WEIGHT_SHIFT = 32.0  # bsg_config.gemm_x3: every Linear weight is stored x 2^5 (exact) so that f16(w) and f16(w - f16(w)) are normal
+
+
+def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, embed_split: bool = False,
+                       gemm_x3: bool = False) -> list[torch.Tensor]:
     """Device tensors in the slot order documented in `include/beach_seg_amd.h`."""
     missing = [k for k in state_dict_shapes(g) if k not in sd]
     if missing:
@@ -101,9 +105,19 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, 
     def f32(x):
         return x.detach().to(device=device, dtype=torch.float32).contiguous()
 
+    def x3(w: torch.Tensor) -> torch.Tensor:
+        """`bsg_config.gemm_x3` weight format: w x 2^5, every 16-byte chunk of a row = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (f16)
+        of its four values -- the bytes of four floats, viewed as float32 so that the table stays one dtype."""
+        w = (w.to(device=device, dtype=torch.float32) * X3_WEIGHT_SHIFT).contiguous()
+        hi = w.half()
+        lo = (w - hi.float()).half()
+        n, k = w.shape
+        packed = torch.cat([hi.view(n, k // 4, 4), lo.view(n, k // 4, 4)], dim=2).contiguous()  # (n, k/4, 8) f16
+        return packed.view(torch.float32).view(n, k)
+
     def lin(name):  # (weight [out][in], weight^T [in][out])
         w = sd[name].detach().to(device=device, dtype=torch.float32)
-        return T(w), T(w.t())
+        return (x3(w), x3(w.t())) if gemm_x3 else (T(w), T(w.t()))
 
     tab_i, tab_s = token_tables(sd, g)
     pw = sd["model.embeddings.patch_embeddings.projection.weight"].reshape(D, -1)
@@ -113,7 +127,8 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, 
     conv_wT = cw.flip(2, 3).permute(1, 2, 3, 0).reshape(dd, 9, dd)  # [ci][tap'][co], taps flipped (dgrad)
     dw, dwT = lin("decoder.decoder_embed.weight")
     pw32 = pw.detach().to(device=device, dtype=torch.float32)
-    patch = (_split3(pw32, dtype), _split3(pw32.t(), dtype)) if embed_split else (T(pw), T(pw.t()))
+    patch = ((_split3(pw32, dtype), _split3(pw32.t(), dtype)) if embed_split else
+             (x3(pw32), x3(pw32.t())) if gemm_x3 else (T(pw32), T(pw32.t())))
     table = [
         patch[0], patch[1], f32(tab_i), f32(tab_s),
         f32(sd["model.encoder.layernorm.weight"]), f32(sd["model.encoder.layernorm.bias"]),
@@ -183,7 +198,7 @@ class SegGptNative(torch.nn.Module):
     runs on a device-chosen power-of-two multiple of the gradient)."""
 
     def __init__(self, state_dict: dict, geometry: SegGptGeometry, device="cuda:0", dtype=torch.bfloat16,
-                 embed_split: Optional[bool] = None):
+                 embed_split: Optional[bool] = None, gemm_x3: bool = False):
         """`embed_split` (16-bit dtypes; default on): patch embedding and its dgrad as split-precision GEMMs, so pixels and
         the prompt-pixel gradient are not quantised to the MFMA operand type (`bsg_config.embed_split`)."""
         super().__init__()
@@ -196,7 +211,12 @@ class SegGptNative(torch.nn.Module):
         self.embed_split = (dtype != torch.float32) if embed_split is None else bool(embed_split)
         if self.embed_split and dtype == torch.float32:
             raise ValueError("embed_split applies to the 16-bit dtypes only")
-        self._table = build_weight_table(state_dict, geometry, dtype, self._device, self.embed_split)
+        # gemm_x3 (float32 only): "float32 at three f16 MFMAs" -- exact-f32 storage / attention / LayerNorm / conv, the Linear
+        # GEMMs on the f16 matrix cores with 22-bit operands (`bsg_config.gemm_x3`)
+        self.gemm_x3 = bool(gemm_x3)
+        if self.gemm_x3 and dtype != torch.float32:
+            raise ValueError("gemm_x3 applies to dtype float32 only")
+        self._table = build_weight_table(state_dict, geometry, dtype, self._device, self.embed_split, self.gemm_x3)
         cfg = N.BsgConfig()
         g = geometry
         cfg.hidden_size, cfg.num_layers, cfg.num_heads = g.hidden_size, g.num_hidden_layers, g.num_attention_heads
@@ -208,6 +228,7 @@ class SegGptNative(torch.nn.Module):
         cfg.layer_norm_eps = g.layer_norm_eps
         cfg.dtype = {torch.float32: N.BSG_DTYPE_F32, torch.bfloat16: N.BSG_DTYPE_BF16, torch.float16: N.BSG_DTYPE_F16}[dtype]
         cfg.embed_split = int(self.embed_split)
+        cfg.gemm_x3 = int(self.gemm_x3)
         ptrs = (C.c_void_p * len(self._table))(*[t.data_ptr() for t in self._table])
         h = C.c_void_p()
         with torch.cuda.device(self._device):
@@ -330,7 +351,7 @@ class SegGptNative(torch.nn.Module):
     def last_backward_overflowed(self) -> bool:
         """f16 only: did the last autograd backward produce a non-finite prompt gradient?  (Host synchronisation, like
         `GradScaler.step`: the caller skips `optimizer.step()` when True.)"""
-        if self.dtype != torch.float16 or self._last_bwd is None:
+        if not (self.dtype == torch.float16 or self.gemm_x3) or self._last_bwd is None:
             return False
         return bool(int(self.grad_overflow_state(*self._last_bwd)[0]))
 

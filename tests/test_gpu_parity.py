@@ -43,6 +43,7 @@ def relmax(a, b):
 
 
 _models = {}
+F32X3 = "float32x3"  # pseudo-dtype of the parametrisations: SegGptNative(dtype=float32, gemm_x3=True)
 
 
 def geometry_of(gname):
@@ -64,7 +65,10 @@ def model_for(gname, wseed, dtype, peak_gain=0.0):
             dev_sd = peaked_state_dict(g, wseed, peak_gain, device=DEV if gname == "vit_large" else "cpu")
         else:
             dev_sd = synth_state_dict(g, seed=wseed, device=DEV if gname == "vit_large" else "cpu")
-        _models[key] = SegGptNative(dev_sd, g, device=DEV, dtype=dtype)
+        if dtype == F32X3:  # float32 storage / attention / LayerNorm, Linear GEMMs as three f16 MFMAs on 22-bit operand splits
+            _models[key] = SegGptNative(dev_sd, g, device=DEV, dtype=torch.float32, gemm_x3=True)
+        else:
+            _models[key] = SegGptNative(dev_sd, g, device=DEV, dtype=dtype)
     return _models[key]
 
 
@@ -110,6 +114,10 @@ TOL = {
     torch.float32: {**{k: dict(t=1e-4, loss=1e-5, mm=0) for k in ("tiny", "tiny_dec128", "small", "small_peaked", "vit_large")},
                     # peaked ViT-L amplifies rounding ~1e3 x (see the 16-bit rows): two fp32 evaluation orders differ by 2.4e-5 / 9.1e-5
                     "vit_large_peaked": dict(t=1e-4, tg=3e-4, loss=1e-5, mm=0)},
+    # float32 with the Linear GEMMs as three f16 MFMAs (22-bit operands; exact-f32 attention / LayerNorm / conv): bars 1e-4 like
+    # exact f32 (measured: see DESIGN.md section 2), masks by the margin rule with at most 2 near-tie pixels
+    F32X3: {**{k: dict(t=1e-4, loss=1e-5, mm=2) for k in ("tiny", "tiny_dec128", "small", "small_peaked", "vit_large")},
+            "vit_large_peaked": dict(t=2e-4, tg=6e-4, loss=1e-5, mm=2)},
     torch.float16: {   # IEEE half operands: ~8x less round-off than bf16; bars set from the measured values below
         "tiny": dict(t=1.2e-3, loss=1e-5, mm=4),          # measured pred 5.2e-4 / grad 7.4e-4, 1 of 8192 mask pixels
         "small": dict(t=1.2e-3, loss=1e-5, mm=2),         # 4.8e-4 / 6.7e-4, 0 of 6272
@@ -133,7 +141,7 @@ TOL = {
 }
 
 
-DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+DTYPES = [torch.float32, F32X3, torch.bfloat16, torch.float16]
 
 
 @pytest.mark.parametrize("gname", ["tiny", "tiny_dec128"])
