@@ -16,6 +16,50 @@
 #define BSG_DIAG_DQ 0  // timing-only ablations of the dQ kernel (wrong results): 1 no softmax VALU, 2 no MFMA, 3 no LDS reads, 4 no DMA/barrier
 #endif
 
+// "float32 at three f16 MFMAs" for the exact-f32 attention kernels (X3 = bsg_config.gemm_x3): each f32 fragment as
+// hi = f16(x), lo = f16(x - hi) (22 significant bits), hi*hi + hi*lo + lo*hi accumulated in fp32 by three
+// v_mfma_f32_32x32x8_f16 (3 x 32 cycles) in place of four v_mfma_f32_32x32x2_f32 (4 x 64 cycles); same fragment geometry
+// (lane = row / column, 4 k-values per lane and half-wave).  Loop-invariant fragments (Q, K, V, dO held in registers) are
+// converted once by the compiler's hoisting; tile fragments once per use.
+DEVI void x3_split(const f32x4& x, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hi[e] = (f16_t)x[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lo[e] = (f16_t)(x[e] - (float)hi[e]);
+}
+DEVI void mma32_x3(f32x16& acc, const f32x4& a, const f32x4& b) {
+  f16x4 ah, al, bh, bl;
+  x3_split(a, ah, al);
+  x3_split(b, bh, bl);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(al, bh, acc, 0, 0, 0);
+#ifndef BSG_X3_NO_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+// a fragment that lives in registers across the key / query loop, split ONCE (same register count as the f32x4 it replaces)
+struct X3Frag { f16x4 hi, lo; };
+DEVI X3Frag x3_frag(const f32x4& x) { X3Frag f; x3_split(x, f.hi, f.lo); return f; }
+template <typename Ch> DEVI Ch x3_frag(const Ch& x) { return x; }  // 16-bit dtypes: the fragment itself
+DEVI void mma32_x3(f32x16& acc, const f32x4& a, const X3Frag& b) {
+  f16x4 ah, al;
+  x3_split(a, ah, al);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x8f16(al, b.hi, acc, 0, 0, 0);
+#ifndef BSG_X3_NO_FENCE
+  // keep the scheduler from hoisting the NEXT iterations' tile reads + splits above these MFMAs: with 16 unrolled (block,
+  // k-step) iterations that parks ~120 split registers and spills (dQ kernel: 480 B of scratch per lane, slower than exact f32)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <bool X3> DEVI void mm32(f32x16& acc, const f32x4& a, const X3Frag& b) { mma32_x3(acc, a, b); }
+template <bool X3, typename Ch> DEVI void mm32(f32x16& acc, const Ch& a, const Ch& b) {
+  if constexpr (X3 && std::is_same<Ch, f32x4>::value) mma32_x3(acc, a, b);
+  else mma32(acc, a, b);
+}
+
 struct AttnArgs {
   const void* q;   // T [S*N][ld] (+ column offset applied by caller) ; head h at columns h*64..
   const void* k;
@@ -298,7 +342,7 @@ DEVI void relpos_wave_bwd(f32x16 (&acc)[2], const void* rel_catT, int hp, int wp
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, bool TR>
+template <typename T, bool TR, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
@@ -365,6 +409,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     dma_tile_issue<T>(kt_l + C::TILE, wave, vtbase + t * vstep, voff);
   };
 
+  // X3: the loop-invariant Q fragments split once; the raw f32 copies die here
+  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
+  LFrag qx[C::KS_D];
+#pragma unroll
+  for (int ks = 0; ks < C::KS_D; ++ks) {
+    if constexpr (X3 && sizeof(T) == 4) qx[ks] = x3_frag(qf[ks]);
+    else qx[ks] = qf[ks];
+  }
   f32x2 rh_next = f32x2{relh_g[0], relh_g[npad]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
@@ -388,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       st[b] = rwv;
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks)
-        mma32(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qf[ks]);
+        mm32<X3>(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qx[ks]);
     }
     // online softmax over this lane's 32 slots (+ partner half-wave); padded key slots carry relw = -inf
     float mx0 = -INFINITY, mx1 = -INFINITY;  // a constant seed: no canonicalising v_max of the first MFMA outputs
@@ -432,8 +484,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         const Chunk pb = acc_chunk(st[b], ks, T());
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          if constexpr (TR) mma32(o[db], lds_tr_chunk<T>(vt_l, db, b, ks, lane), pb);
-          else mma32(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+          if constexpr (TR) mm32<X3>(o[db], lds_tr_chunk<T>(vt_l, db, b, ks, lane), pb);
+          else mm32<X3>(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
         }
       }
   }
@@ -462,7 +514,7 @@ __device__ unsigned long long bsg_attn_stamps[8];
 #else
 #define ATTN_STAMP(i) do {} while (0)
 #endif
-template <typename T, bool TR>
+template <typename T, bool TR, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #ifdef BSG_DIAG_STAMPS_ATTN
   long long st_prev = __builtin_amdgcn_s_memtime();
@@ -557,6 +609,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
   ATTN_STAMP(2);  // delta, DMA offsets
   f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
+  // X3: the loop-invariant Q / dO fragments split once; the raw f32 copies die here
+  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
+  LFrag qx[C::KS_D], dox[C::KS_D];
+#pragma unroll
+  for (int ks = 0; ks < C::KS_D; ++ks) {
+    if constexpr (X3 && sizeof(T) == 4) { qx[ks] = x3_frag(qf[ks]); dox[ks] = x3_frag(dof[ks]); }
+    else { qx[ks] = qf[ks]; dox[ks] = dof[ks]; }
+  }
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -583,14 +643,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
 #if BSG_DIAG_DQ == 3
-        mma32(st, dof[(ks + b) & 3], qf[ks]);
-        mma32(dp, qf[(ks + b) & 3], dof[ks]);
+        mm32<X3>(st, dof[(ks + b) & 3], qf[ks]);
+        mm32<X3>(dp, qf[(ks + b) & 3], dof[ks]);
 #elif BSG_DIAG_DQ == 2
         st[ks] += to_f32(lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h)[0]);
         dp[ks] += to_f32(lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h)[0]);
 #else
-        mma32(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qf[ks]);
-        mma32(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dof[ks]);
+        mm32<X3>(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qx[ks]);
+        mm32<X3>(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dox[ks]);
 #endif
       }
       const float nb = fmaf(rh[b], c2, -lse);
@@ -616,13 +676,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #if BSG_DIAG_DQ == 3
-          if constexpr (TR) mma32(dqt[d], qf[(ks + d) & 3], db_);
+          if constexpr (TR) mm32<X3>(dqt[d], qf[(ks + d) & 3], db_);
 #elif BSG_DIAG_DQ == 2
           if constexpr (TR) dqt[d][ks] += to_f32(lds_tr_chunk<T>(k_l, d, b, ks, lane)[0]) * to_f32(db_[0]);
 #else
-          if constexpr (TR) mma32(dqt[d], lds_tr_chunk<T>(k_l, d, b, ks, lane), db_);
+          if constexpr (TR) mm32<X3>(dqt[d], lds_tr_chunk<T>(k_l, d, b, ks, lane), db_);
 #endif
-          else mma32(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
+          else mm32<X3>(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
         }
       }
     }
@@ -703,7 +763,7 @@ template <typename T, bool TR, int QT = 64> struct DkvK {
 // same LDS-DMA stream as the Q / dO tiles instead of occupying 128 registers.
 // QT = queries per streamed tile (64 or 128): a tile costs one workgroup barrier + one DMA wait for all 8 waves, so the
 // 128-query form halves the synchronisations (112 KB of LDS for the two stages; 16-bit dtypes only).
-template <typename T, bool TR, int QT = 64>
+template <typename T, bool TR, int QT = 64, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
@@ -737,6 +797,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       kf[ks] = *(const Chunk*)(krow + (2 * ks + h) * 16);
       vf[ks] = *(const Chunk*)(vrow + (2 * ks + h) * 16);
     }
+  }
+  // X3: the loop-invariant K / V fragments split once; the raw f32 copies die here
+  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
+  LFrag kx[C::KS_D], vx[C::KS_D];
+#pragma unroll
+  for (int ks = 0; ks < C::KS_D; ++ks) {
+    if constexpr (X3 && sizeof(T) == 4) { kx[ks] = x3_frag(kf[ks]); vx[ks] = x3_frag(vf[ks]); }
+    else { kx[ks] = kf[ks]; vx[ks] = vf[ks]; }
   }
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool key_valid = col < a.wp;
@@ -796,8 +864,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       }
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
-        mma32(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kf[ks]);
-        mma32(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vf[ks]);
+        mm32<X3>(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kx[ks]);
+        mm32<X3>(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vx[ks]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -813,11 +881,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           if constexpr (TR) {
-            mma32(dvt[d], lds_tr_chunk<T>(do_l, d, qa, ks, lane), pb);
-            mma32(dkt[d], lds_tr_chunk<T>(q_l, d, qa, ks, lane), dsb);
+            mm32<X3>(dvt[d], lds_tr_chunk<T>(do_l, d, qa, ks, lane), pb);
+            mm32<X3>(dkt[d], lds_tr_chunk<T>(q_l, d, qa, ks, lane), dsb);
           } else {
-            mma32(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
-            mma32(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
+            mm32<X3>(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
+            mm32<X3>(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
           }
         }
       }

@@ -560,11 +560,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
   };
   auto mfma_quadrant = [&](int mh, int nh, int p) {
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (X3) {  // convert the A fragments this phase's read step fetched: p0 a(mh0), p2 a(mh1)
-      if (p == 0 || p == 2)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (!mh || i < MH1) split_a(i);
+    if constexpr (X3) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const f16x8 w0 = __builtin_bit_cast(f16x8, bf[nh][0][j]), w1 = __builtin_bit_cast(f16x8, bf[nh][1][j]);
@@ -606,6 +602,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if constexpr (X3) {
+        // split the A fragments this phase's read step fetched (p0: rows mh0, p2: rows mh1) HERE, in the load segment: the
+        // partner wave of this SIMD is in its MFMA cluster meanwhile, so the ~100 conversion instructions run under its MFMAs
+        // instead of in front of this wave's own (in the MFMA phase they cost 127 -> measured below)
+        if (p == 0 || p == 2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (p == 0 || i < MH1) split_a(i);
       }
       asm volatile("s_barrier" ::: "memory");
       mfma_quadrant(p >> 1, (p == 1 || p == 2) ? 1 : 0, p);

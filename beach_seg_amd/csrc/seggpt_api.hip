@@ -252,9 +252,18 @@ template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int d
 
 // dK/dV launch: 16-bit dtypes stream 128-query tiles when the padded statistics rows hold the rounded-up length
 // (BSG_DKV_QT=64 forces the 64-query form: A/B runs)
-template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t st) {
+template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t st, bool x3 = false) {
   constexpr bool tr = sizeof(T) == 2;
   const dim3 kgrid(((k.hp + 7) / 8) * k.nh * k.S);
+  if constexpr (!tr) {
+    if (x3) {  // exact-f32 storage, three f16 MFMAs per f32 MFMA quadruple (attention.hpp mma32_x3)
+      constexpr int lds3 = 2 * DkvK<T, false, 64>::STAGE;
+      static bool once3 = (allow_lds(attn_bwd_dkv_kernel<T, false, 64, true>, lds3), true);
+      (void)once3;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false, 64, true>), kgrid, dim3(512), lds3, st, k);
+      return;
+    }
+  }
   if constexpr (tr) {
     static const int qt_env = getenv("BSG_DKV_QT") ? atoi(getenv("BSG_DKV_QT")) : 128;
     if (qt_env == 128 && ((k.N + 127) & ~127) <= k.hp * 32) {
@@ -359,7 +368,16 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       const dim3 agrid(((N + 127) / 128) * nh * S);
       const int relh_lds = 4 * 32 * (hp | 1) * 4;  // prologue scratch (32 x HS relh table per wave) aliases the tiles
       const int lds = std::max(4 * AttnK<T>::TILE, relh_lds);
-      hipLaunchKernelGGL((attn_fwd_kernel<T, tr>), agrid, dim3(256), lds, st, a);
+      bool x3_done = false;
+      if constexpr (!tr) {
+        if (m->c.gemm_x3) {
+          static bool once3 = (allow_lds(attn_fwd_kernel<T, false, true>, 160 * 1024), true);
+          (void)once3;
+          hipLaunchKernelGGL((attn_fwd_kernel<T, false, true>), agrid, dim3(256), lds, st, a);
+          x3_done = true;
+        }
+      }
+      if (!x3_done) hipLaunchKernelGGL((attn_fwd_kernel<T, tr>), agrid, dim3(256), lds, st, a);
       CHECK_LAUNCH();
     }
     {
@@ -565,7 +583,16 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
         ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
         const dim3 qgrid(((N + 127) / 128) * nh * B);
         const int relh_lds = 4 * 32 * (hp | 1) * 4;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, tr>), qgrid, dim3(256), (tr ? 4 : 6) * AttnK<T>::TILE + relh_lds, st, a);
+        bool x3_done = false;
+        if constexpr (!tr) {
+          if (m->c.gemm_x3) {
+            static bool once3 = (allow_lds(attn_bwd_dq_kernel<T, false, true>, 160 * 1024), true);
+            (void)once3;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false, true>), qgrid, dim3(256), 6 * AttnK<T>::TILE + relh_lds, st, a);
+            x3_done = true;
+          }
+        }
+        if (!x3_done) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, tr>), qgrid, dim3(256), (tr ? 4 : 6) * AttnK<T>::TILE + relh_lds, st, a);
       }
       CHECK_LAUNCH();
       AttnBwdKvArgs k{};
@@ -574,7 +601,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
       {
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
-        launch_dkv<T>(k, st);
+        launch_dkv<T>(k, st, m->c.gemm_x3 != 0);
       }
       CHECK_LAUNCH();
     }
