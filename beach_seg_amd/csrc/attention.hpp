@@ -514,8 +514,10 @@ __device__ unsigned long long bsg_attn_stamps[8];
 #else
 #define ATTN_STAMP(i) do {} while (0)
 #endif
+// f32: 6 tiles of 16 KB + the relh table = one workgroup per CU, i.e. one wave per SIMD anyway -> the whole 512-register
+// file is this wave's (the 256-register bound of the 16-bit kernels made the f32 forms spill: 60 B exact, 100 B x3)
 template <typename T, bool TR, bool X3 = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #ifdef BSG_DIAG_STAMPS_ATTN
   long long st_prev = __builtin_amdgcn_s_memtime();
 #endif

@@ -45,10 +45,11 @@ typedef struct bsg_config {
                       activations [hi | hi | lo] against weights [W_hi | W_lo | W_hi] (x = hi + lo in bf16), so the input
                       pixels and the prompt-pixel gradient are not quantised to 8 bits; weight slots 0 / 1 then hold
                       T[D][3*768] / T[768][3*D].  0.6 % of the FLOPs. */
-  int gemm_x3;     /* BSG_DTYPE_F32 only: 1 = "float32 at three f16 MFMAs".  Storage, attention, LayerNorm, conv stay exact f32; the
-                      Linear GEMMs (96 % of the GEMM flops: the 256 x 256 kernel) split every f32 operand fragment in registers
-                      into hi = f16(x), lo = f16(x - hi) and accumulate hi*hi + hi*lo + lo*hi in fp32 (22-bit operands) on the f16
-                      matrix cores -- ~3x the rate of v_mfma_f32_*_f32.  The caller stores every Linear weight (slots 0, 1, 6, 7 and
+  int gemm_x3;     /* BSG_DTYPE_F32 only: 1 = "float32 at three f16 MFMAs".  Storage, softmax, LayerNorm, residual stream and the
+                      3x3 conv stay exact f32; the Linear GEMMs (the 256 x 256 kernel) and the three attention kernels use every
+                      f32 operand fragment as hi = f16(x), lo = f16(x - hi) and accumulate hi*hi + hi*lo + lo*hi in fp32 (22-bit
+                      operands) on the f16 matrix cores -- up to ~3x the rate of v_mfma_f32_*_f32; measured: the errors of the
+                      exact mode on every reference vector at twice its step rate.  The caller stores every Linear weight (slots 0, 1, 6, 7 and
                       2, 3, 5, 6, 10, 11, 13, 14 of a layer) PRE-SPLIT: multiplied by 2^5 (exact; keeps hi and lo in f16's normal
                       range), and every 16-byte chunk of a row holding [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (f16) of its four
                       values in place of the four floats (beach_seg_amd.seggpt.build_weight_table); the library multiplies the

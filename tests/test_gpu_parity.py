@@ -8,6 +8,9 @@ each arithmetic mode delivers, they are not derived from the tolerance.
   * dtype float32 (parity mode, exact-f32 MFMA): max-abs error <= 1e-4 of the tensor's max-abs (measured 1e-6 .. 4e-6; 2.4e-5 /
     9.1e-5 on ViT-L with peaked attention), loss to 1e-5 rel, decoded masks BIT-EXACT.  The one mode inside north_star's bar on
     every fixture.
+  * "float32x3" = dtype float32 with gemm_x3 (every GEMM / attention MFMA as three f16 MFMAs on 22-bit operand splits, f32
+    storage / softmax / LayerNorm): the same errors as exact f32 (1e-6 .. 3e-6; 2.4e-5 / 7.8e-5 on peaked ViT-L) at twice its
+    rate; masks by the margin rule, 0 pixels differ on every fixture.
   * dtype float16 (IEEE-half MFMA operands at the bf16 MFMA rate, fp32 accumulate / residual stream / softmax / LN, the dgrad
     chain on a device-chosen power-of-two multiple of the gradient): 5e-4 .. 7e-4 on the small nets, 1.35e-3 / 1.43e-3 on plain
     ViT-L, 9.4e-3 / 3.2e-2 on ViT-L with PEAKED attention (row-max logit 28-43 above the row mean in all 24 layers).

@@ -7,9 +7,9 @@ from beach_seg_amd.engine import PromptTrainEngine
 from beach_seg_amd.seggpt import SegGptNative
 from beach_seg_amd.weights import SegGptGeometry, synth_state_dict
 g = SegGptGeometry.vit_large(); dev = torch.device("cuda:0")
-for x3 in (False, True):
+for x3 in ((True,) if len(sys.argv) > 2 else (False, True)):
     m = SegGptNative(synth_state_dict(g, seed=0, device=dev), g, device=dev, dtype=torch.float32, gemm_x3=x3)
-    B = 16
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     gen = torch.Generator(device=dev).manual_seed(7)
     rn = lambda: torch.randn(B, 3, 448, 448, device=dev, generator=gen)
     pix, lab, pmc = rn(), rn(), rn()
