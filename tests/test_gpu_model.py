@@ -175,6 +175,36 @@ def test_f16_overflow_guard_skips_the_step_and_backs_off():
     assert not net.last_backward_overflowed() and torch.isfinite(p.grad).all()
 
 
+def test_x3_mode_engine_step_tracks_exact_f32():
+    """`gemm_x3` (float32 storage, every GEMM / attention MFMA as three f16 MFMAs on 22-bit operand splits, the dgrad chain
+    on the device-chosen power-of-two multiple of the gradient): two optimiser steps of the fused engine against the exact-f32
+    mode on the same inputs -- loss to 1e-6, parameters to fp32 round-off -- and the precision string "32-x3" selects it."""
+    geo = SegGptGeometry.tiny()
+    sd = synth_state_dict(geo, seed=1)
+    g = torch.Generator().manual_seed(8)
+    P0 = torch.rand(3, 3, 64, 64, generator=g)
+    pix = ml_util.normalize(torch.rand(2, 3, 64, 64, generator=g)).to(DEV)
+    lab = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    pmc = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    yes = torch.ones(2, 1, 64, 64, dtype=torch.bool, device=DEV)
+    idx = torch.tensor([2, 0], device=DEV)
+    res = []
+    for x3 in (False, True):
+        net = SegGptNative(sd, geo, device=DEV, dtype=torch.float32, gemm_x3=x3)
+        eng = PromptTrainEngine(net, P0, lr=1e-2)
+        losses = [eng.step(pix, lab, yes, idx, pmc) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert int(eng.skipped_steps) == 0
+        res.append((torch.stack(losses).cpu(), eng.params.cpu()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-6, atol=0)
+    assert float((res[0][1] - res[1][1]).abs().max()) < 2e-5  # two AdamW steps of lr 1e-2: sign-level agreement of the updates
+    conf = BeachSegConfig(batch_size=2, checkpoint="synthetic:tiny", precision="32-x3", inpt_size=64, crop_size=64)
+    pm = PromptModel(conf)
+    assert pm.model.dtype == torch.float32 and pm.model.gemm_x3
+    with pytest.raises(ValueError):
+        SegGptNative(sd, geo, device=DEV, dtype=torch.bfloat16, gemm_x3=True)
+
+
 def test_validation_forward_and_predict_mosaic():
     geo = SegGptGeometry.tiny()
     net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float32)
