@@ -333,8 +333,9 @@ def main() -> None:
                                       "tflops": round(Bx / tx * TRAIN_FLOPS_PER_TILE / 1e12, 1),
                                       "peak_tflops": PEAK_BF16_TFLOPS if key == "f16" else 157.3, "loss_finite": bool(torch.isfinite(lx))}
                 if key == "f32x3":
-                    out[f"{key}_mode"]["note"] = ("GEMMs (80 % of the flops) at 3 f16 MFMAs per exact-f32 MFMA quadruple; attention / conv on "
-                                                  "exact-f32 MFMA: no single peak applies, peak_tflops is the f32 MFMA peak")
+                    out[f"{key}_mode"]["note"] = ("float32 storage / softmax / LayerNorm; every GEMM and attention MFMA as three f16 MFMAs on "
+                                                  "22-bit operand splits (conv on exact-f32 MFMA): same parity as f32_parity; no single peak "
+                                                  "applies, peak_tflops is the exact-f32 MFMA peak it replaces")
                 log(f"{key} mode: {tx * 1e3:.0f} ms/step at B={Bx} = {Bx / tx:.1f} tiles/s")
                 del ex, mx
                 torch.cuda.empty_cache()
