@@ -530,7 +530,7 @@ def test_feature_ensemble_vs_reference_vector(golden_dir, dtype):
         assert (got.cpu() == want).float().mean().item() > 0.99  # pred differs from HF's by ~1e-6: near-ties may flip
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, F32X3, torch.bfloat16, torch.float16])
 def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
     """BASELINE config 5 geometry (`SegGptGeometry.config5`): 64 x 32 token grid (1024 x 512 canvas: no padded key slots, Hp =
     64), a 2048-wide encoder with 32 heads and the 128-channel decoder; 2 layers so the CPU oracle finishes in seconds.  No reference checkpoint of this
@@ -545,7 +545,8 @@ def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
     assert (g.hidden_size, g.num_attention_heads, g.image_size, g.decoder_hidden_size) == (2048, 32, (1024, 512), 128)
     _models.clear()
     sd = synth_state_dict(g, seed=5)
-    model = SegGptNative(sd, g, device=DEV, dtype=dtype)
+    model = (SegGptNative(sd, g, device=DEV, dtype=torch.float32, gemm_x3=True) if dtype == F32X3 else
+             SegGptNative(sd, g, device=DEV, dtype=dtype))
     pix, prm, pm_cls, lb_cls, pal = synth_inputs(g, 1, 9)
     pm = O.normalize(O.apply_mask_rgb(pal, pm_cls))
     lab = O.normalize(O.apply_mask_rgb(pal, lb_cls))
@@ -559,7 +560,7 @@ def test_wide_grid_and_wide_encoder_vs_oracle(dtype):
     loss = ops.seggpt_loss(out.pred_masks, lab.to(DEV), yes.to(DEV), 0.01, "reference")
     loss.backward()
     # bf16, 2 wide layers: measured 7.3e-3 / 7.3e-3 (decoder 64); f16 ~8x below
-    t, tl = {torch.float32: (1e-4, 1e-5), torch.bfloat16: (1.2e-2, 1e-3), torch.float16: (2e-3, 1e-5)}[dtype]
+    t, tl = {torch.float32: (1e-4, 1e-5), F32X3: (1e-4, 1e-5), torch.bfloat16: (1.2e-2, 1e-3), torch.float16: (2e-3, 1e-5)}[dtype]
     print(f"[measured] config-5 class {dtype}: pred {relmax(out.pred_masks, pred_ref):.2e} grad {relmax(p.grad, grad_ref):.2e}")
     assert relmax(out.pred_masks, pred_ref) < t
     assert abs(loss.item() - loss_ref.item()) < tl * abs(loss_ref.item())
