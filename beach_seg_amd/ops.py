@@ -122,6 +122,8 @@ def mask_rgb_norm(palette: torch.Tensor, class_ids: torch.Tensor, mean=IMAGE_MEA
     B, h, w = ids.shape
     ids = ids.to(torch.uint8).contiguous()
     out = torch.empty((B, 3, h, w), dtype=torch.float32, device=ids.device)
+    if out.numel() == 0:  # empty batch / empty plane: torch's gather returns the empty tensor, nothing to launch
+        return out
     with torch.cuda.device(ids.device):
         N.check(lib.bsg_mask_rgb_norm(_stream(), B, h, w, palette.shape[1], _ptr(ids), _ptr(palette.contiguous()), _f3(mean),
                                       _f3(std), _ptr(out)))
