@@ -156,7 +156,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="tiles per GPU per step (default: 64; 32 for --geometry config5)")
     ap.add_argument("--prompts", type=int, default=64, help="number of learnable prompt images P")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32x3"],
+                    help="bf16: BASELINE configs[1], the headline; f32x3: float32 storage with every GEMM / attention MFMA as three "
+                         "f16 MFMAs on 22-bit operand splits (the fast mode inside the reference's 1e-3); f32: exact-f32 MFMA")
     ap.add_argument("--geometry", default="vit_large", help="vit_large (BASELINE configs[1], the headline) | config5 (configs[4]: "
                     "1024x512 canvas, hidden 2048, 32 heads, decoder 128) | tiny | small")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -196,12 +198,12 @@ def main() -> None:
         args.batch = 32 if args.geometry == "config5" else 64
     fwd_flops, bwd_flops = flops_per_tile(g)
     train_flops = fwd_flops + bwd_flops
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": torch.float32}[args.dtype]
     log(f"rank {rank}/{world}: building {args.geometry} ({args.dtype}) on {dev}")
     # BSG_BENCH_CPU_WEIGHTS: build the (bit-identical) synthetic weights on the host -- under rocprofv3 --pmc the
     # thousands of tiny generator kernels would otherwise dominate the profiling run
     wdev = torch.device("cpu") if os.environ.get("BSG_BENCH_CPU_WEIGHTS") else dev
-    model = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dtype)
+    model = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dtype, gemm_x3=args.dtype == "f32x3")
     log("model ready")
     B, P = args.batch, args.prompts
     Hh, W = g.image_size[0] // 2, g.image_size[1]
