@@ -881,9 +881,13 @@ int bsg_adamw_step(void* stream, int n_active, long row_elems, float* params, co
 
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias, void* out) {
   if (!A || !W || !out) return fail("bsg_op_gemm: null argument");
-  if (dtype != BSG_DTYPE_F32 && dtype != BSG_DTYPE_BF16 && dtype != BSG_DTYPE_F16) return fail("bsg_op_gemm: dtype must be 0 (f32), 1 (bf16) or 2 (f16)");
+  const bool x3 = dtype == 3;  // f32 operands, W in the pre-split x3 format of bsg_config.gemm_x3 (N > 192: the 256 x 256 kernel)
+  if (x3) dtype = BSG_DTYPE_F32;
+  if (dtype != BSG_DTYPE_F32 && dtype != BSG_DTYPE_BF16 && dtype != BSG_DTYPE_F16) return fail("bsg_op_gemm: dtype must be 0 (f32), 1 (bf16), 2 (f16) or 3 (f32, x3 weights)");
   if (K % (dtype == BSG_DTYPE_F32 ? 32 : 64) || N % 4) return fail("bsg_op_gemm: K must be a multiple of the 128-byte K tile, N of 4");
+  if (x3 && N <= 192) return fail("bsg_op_gemm: the x3 form exists for the 256 x 256 kernel only (N > 192)");
   bsg_model dummy{};
+  dummy.c.gemm_x3 = x3 ? 1 : 0;
   GemmArgs g{};
   g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.out = out; g.ldo = N;
   hipStream_t st = (hipStream_t)stream;

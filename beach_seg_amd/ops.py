@@ -290,17 +290,31 @@ def post_process_semantic_segmentation(pred_masks: torch.Tensor, num_labels: int
 _DTYPE_CODE = {torch.float32: N.BSG_DTYPE_F32, torch.bfloat16: N.BSG_DTYPE_BF16, torch.float16: N.BSG_DTYPE_F16}
 
 
-def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16 or both f32."""
+def x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """f32 (N, K) -> the pre-split weight format of `bsg_config.gemm_x3`: w x 2^5, every 16-byte chunk of a row holding
+    [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (f16) of its four values, viewed as float32 (N, K)."""
+    w = (w.detach().float() * 32.0).contiguous()
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    n, k = w.shape
+    return torch.cat([hi.view(n, k // 4, 4), lo.view(n, k // 4, 4)], dim=2).contiguous().view(torch.float32).view(n, k)
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, x3: bool = False) -> torch.Tensor:
+    """out = a @ w.T (+ bias) on the hand-written MFMA GEMM: a (M,K), w (N,K), both bf16, both f16 or both f32.  `x3` (f32
+    only): three f16 MFMAs on 22-bit operand splits instead of exact-f32 MFMAs (the weight is pre-split here)."""
     _need_gpu(a, w, bias)
     lib = N.load()
     if a.dtype != w.dtype or a.dtype not in _DTYPE_CODE:
         raise ValueError("a and w must both be float32, both bfloat16 or both float16")
+    if x3 and a.dtype != torch.float32:
+        raise ValueError("x3 applies to float32 operands")
     M, K = a.shape
     out = torch.empty((M, w.shape[0]), dtype=a.dtype, device=a.device)
+    wk = x3_weight(w) if x3 else w.contiguous()
     with torch.cuda.device(a.device):
-        N.check(lib.bsg_op_gemm(_stream(), _DTYPE_CODE[a.dtype], M, w.shape[0], K, _ptr(a.contiguous()),
-                                _ptr(w.contiguous()), _ptr(bias), _ptr(out)))
+        N.check(lib.bsg_op_gemm(_stream(), 3 if x3 else _DTYPE_CODE[a.dtype], M, w.shape[0], K, _ptr(a.contiguous()),
+                                _ptr(wk), _ptr(bias), _ptr(out)))
     return out
 
 

@@ -105,15 +105,10 @@ def build_weight_table(sd: dict, g: SegGptGeometry, dtype: torch.dtype, device, 
     def f32(x):
         return x.detach().to(device=device, dtype=torch.float32).contiguous()
 
-    def x3(w: torch.Tensor) -> torch.Tensor:
-        """`bsg_config.gemm_x3` weight format: w x 2^5, every 16-byte chunk of a row = [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] (f16)
-        of its four values -- the bytes of four floats, viewed as float32 so that the table stays one dtype."""
-        w = (w.to(device=device, dtype=torch.float32) * X3_WEIGHT_SHIFT).contiguous()
-        hi = w.half()
-        lo = (w - hi.float()).half()
-        n, k = w.shape
-        packed = torch.cat([hi.view(n, k // 4, 4), lo.view(n, k // 4, 4)], dim=2).contiguous()  # (n, k/4, 8) f16
-        return packed.view(torch.float32).view(n, k)
+    def x3(w: torch.Tensor) -> torch.Tensor:  # `bsg_config.gemm_x3` weight format (ops.x3_weight), on the target device
+        from .ops import x3_weight
+
+        return x3_weight(w.to(device=device, dtype=torch.float32))
 
     def lin(name):  # (weight [out][in], weight^T [in][out])
         w = sd[name].detach().to(device=device, dtype=torch.float32)

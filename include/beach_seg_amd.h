@@ -220,7 +220,8 @@ int bsg_confusion_update(void* stream, long n, int K, int ignore_index, const in
                          const uint8_t* target, uint64_t* confmat);
 
 /* The NT GEMM kernel on its own (unit tests and micro-benchmarks): out[M][N] = A[M][K] W[N][K]^T (+ bias[N]),
- * A / W / out in the dtype given (BSG_DTYPE_*), bias f32 or NULL. */
+ * A / W / out in the dtype given (BSG_DTYPE_*), bias f32 or NULL.  dtype 3: f32 A / out with W in the pre-split format of
+ * bsg_config.gemm_x3 (three f16 MFMAs on 22-bit operand splits; N > 192). */
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,
                 void* out);
 

@@ -34,6 +34,24 @@ def test_gemm_nt_vs_torch(dtype, M, N, K):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256), (25000, 1024, 192)])
+def test_gemm_x3_vs_exact(M, N, K):
+    """`gemm_nt_kernel_v3<float, ..., X3>`: float32 operands as hi = f16(x), lo = f16(x - hi), three f16 MFMAs per exact-f32
+    group (bsg_config.gemm_x3), weights pre-split by the host: against a float64 product -- 22-bit operands leave ~2^-21 of
+    the row norm, i.e. within a small factor of the exact-f32 kernel's own error -- on full, ragged-M, ragged-N and multi-round
+    shapes, with and without the bias epilogue."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.rand(M, K, device=DEV, generator=g) * 2 - 1
+    w = (torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * 0.05  # weight-like magnitudes: lo parts need the 2^5 pre-scale
+    b = torch.randn(N, device=DEV, generator=g)
+    ref = a.double() @ w.double().t()
+    exact, x3, x3b = ops.gemm_nt(a, w), ops.gemm_nt(a, w, x3=True), ops.gemm_nt(a, w, b, x3=True)
+    e_exact, e_x3 = rel(exact, ref), rel(x3, ref)
+    print(f"[measured] gemm x3 {M}x{N}x{K}: exact-f32 kernel {e_exact:.1e}, x3 {e_x3:.1e}")
+    assert e_x3 < 2e-6 and rel(x3b, ref + b.double()) < 2e-6 and e_exact < 2e-6
+    assert torch.isfinite(x3).all()
+
+
 def _attention_reference(qkv, rel_h, rel_w, dout, S, nh, hp, wp):
     N, D = hp * wp, nh * 64
     x = qkv.float().reshape(S, N, 3, nh, 64).permute(2, 0, 3, 1, 4)
