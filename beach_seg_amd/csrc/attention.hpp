@@ -55,6 +55,29 @@ DEVI void mma32_x3(f32x16& acc, const f32x4& a, const X3Frag& b) {
 #endif
 }
 template <bool X3> DEVI void mm32(f32x16& acc, const f32x4& a, const X3Frag& b) { mma32_x3(acc, a, b); }
+// Two f32 k-steps (8 + 8 k-values) side by side = one operand of `v_mfma_f32_32x32x16_f16`, which runs at the full f16 rate on
+// gfx950 (the K = 8 form above takes the same 32 cycles for half the k-values).  The k-order inside the instruction is
+// (first chunk | second chunk) on BOTH operands, so the contraction is the same sum.
+struct X3Frag8 { f16x8 hi, lo; };
+DEVI X3Frag8 x3_frag8(const f32x4& x0, const f32x4& x1) {
+  X3Frag8 f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f16_t h0 = (f16_t)x0[e], h1 = (f16_t)x1[e];
+    f.hi[e] = h0; f.hi[4 + e] = h1;
+    f.lo[e] = (f16_t)(x0[e] - (float)h0); f.lo[4 + e] = (f16_t)(x1[e] - (float)h1);
+  }
+  return f;
+}
+template <typename Ch> DEVI Ch x3_frag8(const Ch& x, const Ch&) { return x; }  // never used for the 16-bit dtypes (keeps `if constexpr` bodies well-formed)
+DEVI void mma32_x3_pair(f32x16& acc, const X3Frag8& a, const X3Frag8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+#ifndef BSG_X3_NO_FENCE
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 template <bool X3, typename Ch> DEVI void mm32(f32x16& acc, const Ch& a, const Ch& b) {
   if constexpr (X3 && std::is_same<Ch, f32x4>::value) mma32_x3(acc, a, b);
   else mma32(acc, a, b);
@@ -410,12 +433,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   };
 
   // X3: the loop-invariant Q fragments split once; the raw f32 copies die here
-  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
-  LFrag qx[C::KS_D];
+  constexpr bool X3f = X3 && sizeof(T) == 4;
+  typedef typename std::conditional<X3f, X3Frag8, Chunk>::type LFrag;
+  LFrag qx[X3f ? C::KS_D / 2 : C::KS_D];
+  if constexpr (X3f) {
 #pragma unroll
-  for (int ks = 0; ks < C::KS_D; ++ks) {
-    if constexpr (X3 && sizeof(T) == 4) qx[ks] = x3_frag(qf[ks]);
-    else qx[ks] = qf[ks];
+    for (int j = 0; j < C::KS_D / 2; ++j) qx[j] = x3_frag8(qf[2 * j], qf[2 * j + 1]);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) qx[ks] = qf[ks];
   }
   f32x2 rh_next = f32x2{relh_g[0], relh_g[npad]};
   issue(0, 0);
@@ -438,9 +464,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       st[b] = rwv;
+      if constexpr (X3f) {
 #pragma unroll
-      for (int ks = 0; ks < C::KS_D; ++ks)
-        mm32<X3>(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qx[ks]);
+        for (int j = 0; j < C::KS_D / 2; ++j)
+          mma32_x3_pair(st[b], x3_frag8(lds_chunk<T>(kt_l, 32 * b + col, 4 * j + h), lds_chunk<T>(kt_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < C::KS_D; ++ks)
+          mm32<false>(st[b], lds_chunk<T>(kt_l, 32 * b + col, 2 * ks + h), qx[ks]);
+      }
     }
     // online softmax over this lane's 32 slots (+ partner half-wave); padded key slots carry relw = -inf
     float mx0 = -INFINITY, mx1 = -INFINITY;  // a constant seed: no canonicalising v_max of the first MFMA outputs
@@ -478,16 +510,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     l += ps;
     // O^T[d][q] += V^T[d][slot] P^T[slot][q]
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b) {
+      if constexpr (X3f) {
 #pragma unroll
-      for (int ks = 0; ks < C::KS_B; ++ks) {
-        const Chunk pb = acc_chunk(st[b], ks, T());
+        for (int j = 0; j < C::KS_B / 2; ++j) {
+          const X3Frag8 pb = x3_frag8(acc_chunk(st[b], 2 * j, T()), acc_chunk(st[b], 2 * j + 1, T()));
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          if constexpr (TR) mm32<X3>(o[db], lds_tr_chunk<T>(vt_l, db, b, ks, lane), pb);
-          else mm32<X3>(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+          for (int db = 0; db < 2; ++db)
+            mma32_x3_pair(o[db], x3_frag8(lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j, h, T()),
+                                          lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j + 1, h, T())), pb);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < C::KS_B; ++ks) {
+          const Chunk pb = acc_chunk(st[b], ks, T());
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            if constexpr (TR) mm32<false>(o[db], lds_tr_chunk<T>(vt_l, db, b, ks, lane), pb);
+            else mm32<false>(o[db], lds_perm_chunk(vt_l, 32 * db + col, b, ks, h, T()), pb);
+          }
         }
       }
+    }
   }
   l += __shfl_xor(l, 32, 64);
   if (q0 + col < a.N) {
@@ -612,12 +656,15 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
   ATTN_STAMP(2);  // delta, DMA offsets
   f32x2 rh_next = f32x2{relh_q[0], relh_q[1]};
   // X3: the loop-invariant Q / dO fragments split once; the raw f32 copies die here
-  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
-  LFrag qx[C::KS_D], dox[C::KS_D];
+  constexpr bool X3f = X3 && sizeof(T) == 4;
+  typedef typename std::conditional<X3f, X3Frag8, Chunk>::type LFrag;
+  LFrag qx[X3f ? C::KS_D / 2 : C::KS_D], dox[X3f ? C::KS_D / 2 : C::KS_D];
+  if constexpr (X3f) {
 #pragma unroll
-  for (int ks = 0; ks < C::KS_D; ++ks) {
-    if constexpr (X3 && sizeof(T) == 4) { qx[ks] = x3_frag(qf[ks]); dox[ks] = x3_frag(dof[ks]); }
-    else { qx[ks] = qf[ks]; dox[ks] = dof[ks]; }
+    for (int j = 0; j < C::KS_D / 2; ++j) { qx[j] = x3_frag8(qf[2 * j], qf[2 * j + 1]); dox[j] = x3_frag8(dof[2 * j], dof[2 * j + 1]); }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) { qx[ks] = qf[ks]; dox[ks] = dof[ks]; }
   }
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
@@ -642,18 +689,26 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       f32x16 st = rwv, dp = ndl;  // S^T accumulator starts at relw (column bias), dP^T at -delta
+      if constexpr (X3f) {
+#pragma unroll
+        for (int j = 0; j < C::KS_D / 2; ++j) {
+          mma32_x3_pair(st, x3_frag8(lds_chunk<T>(k_l, 32 * b + col, 4 * j + h), lds_chunk<T>(k_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
+          mma32_x3_pair(dp, x3_frag8(lds_chunk<T>(v_l, 32 * b + col, 4 * j + h), lds_chunk<T>(v_l, 32 * b + col, 4 * j + 2 + h)), dox[j]);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < C::KS_D; ++ks) {
 #if BSG_DIAG_DQ == 3
-        mm32<X3>(st, dof[(ks + b) & 3], qf[ks]);
-        mm32<X3>(dp, qf[(ks + b) & 3], dof[ks]);
+        mm32<false>(st, dof[(ks + b) & 3], qf[ks]);
+        mm32<false>(dp, qf[(ks + b) & 3], dof[ks]);
 #elif BSG_DIAG_DQ == 2
         st[ks] += to_f32(lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h)[0]);
         dp[ks] += to_f32(lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h)[0]);
 #else
-        mm32<X3>(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qx[ks]);
-        mm32<X3>(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dox[ks]);
+        mm32<false>(st, lds_chunk<T>(k_l, 32 * b + col, 2 * ks + h), qx[ks]);
+        mm32<false>(dp, lds_chunk<T>(v_l, 32 * b + col, 2 * ks + h), dox[ks]);
 #endif
+      }
       }
       const float nb = fmaf(rh[b], c2, -lse);
       float sum = 0.f;
@@ -672,20 +727,31 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
 #endif
       }
       drh[b] = sum + __shfl_xor(sum, 32, 64);
+      if constexpr (X3f) {
+#pragma unroll
+        for (int j = 0; j < C::KS_B / 2; ++j) {
+          const X3Frag8 db8 = x3_frag8(acc_chunk(st, 2 * j, T()), acc_chunk(st, 2 * j + 1, T()));
+#pragma unroll
+          for (int d = 0; d < 2; ++d)
+            mma32_x3_pair(dqt[d], x3_frag8(lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j, h, T()),
+                                           lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j + 1, h, T())), db8);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) {
         const Chunk db_ = acc_chunk(st, ks, T());
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #if BSG_DIAG_DQ == 3
-          if constexpr (TR) mm32<X3>(dqt[d], qf[(ks + d) & 3], db_);
+          if constexpr (TR) mm32<false>(dqt[d], qf[(ks + d) & 3], db_);
 #elif BSG_DIAG_DQ == 2
           if constexpr (TR) dqt[d][ks] += to_f32(lds_tr_chunk<T>(k_l, d, b, ks, lane)[0]) * to_f32(db_[0]);
 #else
-          if constexpr (TR) mm32<X3>(dqt[d], lds_tr_chunk<T>(k_l, d, b, ks, lane), db_);
+          if constexpr (TR) mm32<false>(dqt[d], lds_tr_chunk<T>(k_l, d, b, ks, lane), db_);
 #endif
-          else mm32<X3>(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
+          else mm32<false>(dqt[d], lds_perm_chunk(kt_l, 32 * d + col, b, ks, h, T()), db_);
         }
+      }
       }
     }
     if (h == 0) { relh_q[2 * t] = drh[0]; relh_q[2 * t + 1] = drh[1]; }  // both were read a tile ago
@@ -801,12 +867,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
     }
   }
   // X3: the loop-invariant K / V fragments split once; the raw f32 copies die here
-  typedef typename std::conditional<X3 && sizeof(T) == 4, X3Frag, Chunk>::type LFrag;
-  LFrag kx[C::KS_D], vx[C::KS_D];
+  constexpr bool X3f = X3 && sizeof(T) == 4;
+  typedef typename std::conditional<X3f, X3Frag8, Chunk>::type LFrag;
+  LFrag kx[X3f ? C::KS_D / 2 : C::KS_D], vx[X3f ? C::KS_D / 2 : C::KS_D];
+  if constexpr (X3f) {
 #pragma unroll
-  for (int ks = 0; ks < C::KS_D; ++ks) {
-    if constexpr (X3 && sizeof(T) == 4) { kx[ks] = x3_frag(kf[ks]); vx[ks] = x3_frag(vf[ks]); }
-    else { kx[ks] = kf[ks]; vx[ks] = vf[ks]; }
+    for (int j = 0; j < C::KS_D / 2; ++j) { kx[j] = x3_frag8(kf[2 * j], kf[2 * j + 1]); vx[j] = x3_frag8(vf[2 * j], vf[2 * j + 1]); }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < C::KS_D; ++ks) { kx[ks] = kf[ks]; vx[ks] = vf[ks]; }
   }
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool key_valid = col < a.wp;
@@ -864,10 +933,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st[4 * i + j] = rw[j]; dp[4 * i + j] = dl4[j]; }  // S starts from relwT, dP from -delta
       }
+      if constexpr (X3f) {
 #pragma unroll
-      for (int ks = 0; ks < C::KS_D; ++ks) {
-        mm32<X3>(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kx[ks]);
-        mm32<X3>(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vx[ks]);
+        for (int j = 0; j < C::KS_D / 2; ++j) {
+          mma32_x3_pair(st, x3_frag8(lds_chunk<T>(q_l, 32 * qa + col, 4 * j + h), lds_chunk<T>(q_l, 32 * qa + col, 4 * j + 2 + h)), kx[j]);
+          mma32_x3_pair(dp, x3_frag8(lds_chunk<T>(do_l, 32 * qa + col, 4 * j + h), lds_chunk<T>(do_l, 32 * qa + col, 4 * j + 2 + h)), vx[j]);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < C::KS_D; ++ks) {
+          mm32<false>(st, lds_chunk<T>(q_l, 32 * qa + col, 2 * ks + h), kx[ks]);
+          mm32<false>(dp, lds_chunk<T>(do_l, 32 * qa + col, 2 * ks + h), vx[ks]);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -876,6 +953,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
         st[r] = p;                                   // P
         dp[r] = p * dp[r];                           // dS = P (dP - delta)
       }
+      if constexpr (X3f) {
+#pragma unroll
+        for (int j = 0; j < C::KS_B / 2; ++j) {
+          const X3Frag8 pb = x3_frag8(acc_chunk(st, 2 * j, T()), acc_chunk(st, 2 * j + 1, T()));
+          const X3Frag8 dsb = x3_frag8(acc_chunk(dp, 2 * j, T()), acc_chunk(dp, 2 * j + 1, T()));
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            mma32_x3_pair(dvt[d], x3_frag8(lds_perm_chunk(dot_l, 32 * d + col, qa, 2 * j, h, T()),
+                                           lds_perm_chunk(dot_l, 32 * d + col, qa, 2 * j + 1, h, T())), pb);
+            mma32_x3_pair(dkt[d], x3_frag8(lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j, h, T()),
+                                           lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j + 1, h, T())), dsb);
+          }
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < C::KS_B; ++ks) {
         const Chunk pb = acc_chunk(st, ks, T());
@@ -883,13 +974,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           if constexpr (TR) {
-            mm32<X3>(dvt[d], lds_tr_chunk<T>(do_l, d, qa, ks, lane), pb);
-            mm32<X3>(dkt[d], lds_tr_chunk<T>(q_l, d, qa, ks, lane), dsb);
+            mm32<false>(dvt[d], lds_tr_chunk<T>(do_l, d, qa, ks, lane), pb);
+            mm32<false>(dkt[d], lds_tr_chunk<T>(q_l, d, qa, ks, lane), dsb);
           } else {
-            mm32<X3>(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
-            mm32<X3>(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
+            mm32<false>(dvt[d], lds_perm_chunk(dot_l, 32 * d + col, qa, ks, h, T()), pb);
+            mm32<false>(dkt[d], lds_perm_chunk(qt_l, 32 * d + col, qa, ks, h, T()), dsb);
           }
         }
+      }
       }
     }
   }
