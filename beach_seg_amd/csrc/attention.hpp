@@ -70,6 +70,35 @@ DEVI X3Frag8 x3_frag8(const f32x4& x0, const f32x4& x1) {
   return f;
 }
 template <typename Ch> DEVI Ch x3_frag8(const Ch& x, const Ch&) { return x; }  // never used for the 16-bit dtypes (keeps `if constexpr` bodies well-formed)
+// x3 mode: q / k / v live in HBM as PACKED pairs -- each float slot of the qkv buffer holds (f16 hi | f16 lo << 16), written by
+// the QKV projection's epilogue (gemm.hpp pack_hl) -- so every copy or transpose of 4-byte elements keeps the pairs, and an
+// operand half is two byte-permutes per chunk instead of a 12-instruction split repeated by every workgroup that reads the tile.
+DEVI X3Frag8 x3_frag8_pk(const f32x4& c0, const f32x4& c1) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 a = __builtin_bit_cast(u32x4, c0), b = __builtin_bit_cast(u32x4, c1);
+  u32x4 hi, lo;  // 8 halves each: (a0 a1 | a2 a3 | b0 b1 | b2 b3)
+  hi[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); lo[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u);
+  hi[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u); lo[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+  hi[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); lo[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u);
+  hi[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u); lo[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+  X3Frag8 f;
+  f.hi = __builtin_bit_cast(f16x8, hi);
+  f.lo = __builtin_bit_cast(f16x8, lo);
+  return f;
+}
+template <typename Ch> DEVI Ch x3_frag8_pk(const Ch& x, const Ch&) { return x; }
+DEVI f32x4 x3_unpack(const f32x4& c) {  // packed pairs -> the float values (hi + lo is exact)
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 a = __builtin_bit_cast(u32x4, c);
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned u = a[e];  // (bit_cast of the vector element itself to f16x2 miscompiles: every lane reads element 0)
+    v[e] = (float)__builtin_bit_cast(f16_t, (unsigned short)(u & 0xffffu)) + (float)__builtin_bit_cast(f16_t, (unsigned short)(u >> 16));
+  }
+  return v;
+}
+template <typename Ch> DEVI Ch x3_unpack(const Ch& x) { return x; }
 DEVI void mma32_x3_pair(f32x16& acc, const X3Frag8& a, const X3Frag8& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
@@ -388,7 +417,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
   {
     const char* qrow = (const char*)a.q + (((long)s * a.N + q) * a.ld + head * 64) * sizeof(T);
 #pragma unroll
-    for (int ks = 0; ks < C::KS_D; ++ks) qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+    for (int ks = 0; ks < C::KS_D; ++ks) {
+      qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+      if constexpr (X3 && sizeof(T) == 4) qf[ks] = x3_unpack(qf[ks]);  // x3: qkv holds packed (hi, lo) pairs
+    }
   }
   // rel-pos bias of this wave's 32 queries.  The tile area doubles as the shear scratch before the first DMA; the
   // row part goes out to a key-major global scratch [kh][token] (coalesced both ways, L2-resident: written here,
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
       if constexpr (X3f) {
 #pragma unroll
         for (int j = 0; j < C::KS_D / 2; ++j)
-          mma32_x3_pair(st[b], x3_frag8(lds_chunk<T>(kt_l, 32 * b + col, 4 * j + h), lds_chunk<T>(kt_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
+          mma32_x3_pair(st[b], x3_frag8_pk(lds_chunk<T>(kt_l, 32 * b + col, 4 * j + h), lds_chunk<T>(kt_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < C::KS_D; ++ks)
@@ -517,8 +549,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
           const X3Frag8 pb = x3_frag8(acc_chunk(st[b], 2 * j, T()), acc_chunk(st[b], 2 * j + 1, T()));
 #pragma unroll
           for (int db = 0; db < 2; ++db)
-            mma32_x3_pair(o[db], x3_frag8(lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j, h, T()),
-                                          lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j + 1, h, T())), pb);
+            mma32_x3_pair(o[db], x3_frag8_pk(lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j, h, T()),
+                                             lds_perm_chunk(vt_l, 32 * db + col, b, 2 * j + 1, h, T())), pb);
         }
       } else {
 #pragma unroll
@@ -589,6 +621,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) {
       qf[ks] = *(const Chunk*)(qrow + (2 * ks + h) * 16);
+      if constexpr (X3 && sizeof(T) == 4) qf[ks] = x3_unpack(qf[ks]);  // x3: qkv holds packed (hi, lo) pairs; dO is plain f32
       dof[ks] = *(const Chunk*)(drow + (2 * ks + h) * 16);
     }
   }
@@ -692,8 +725,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
       if constexpr (X3f) {
 #pragma unroll
         for (int j = 0; j < C::KS_D / 2; ++j) {
-          mma32_x3_pair(st, x3_frag8(lds_chunk<T>(k_l, 32 * b + col, 4 * j + h), lds_chunk<T>(k_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
-          mma32_x3_pair(dp, x3_frag8(lds_chunk<T>(v_l, 32 * b + col, 4 * j + h), lds_chunk<T>(v_l, 32 * b + col, 4 * j + 2 + h)), dox[j]);
+          mma32_x3_pair(st, x3_frag8_pk(lds_chunk<T>(k_l, 32 * b + col, 4 * j + h), lds_chunk<T>(k_l, 32 * b + col, 4 * j + 2 + h)), qx[j]);
+          mma32_x3_pair(dp, x3_frag8_pk(lds_chunk<T>(v_l, 32 * b + col, 4 * j + h), lds_chunk<T>(v_l, 32 * b + col, 4 * j + 2 + h)), dox[j]);
         }
       } else {
 #pragma unroll
@@ -733,8 +766,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
           const X3Frag8 db8 = x3_frag8(acc_chunk(st, 2 * j, T()), acc_chunk(st, 2 * j + 1, T()));
 #pragma unroll
           for (int d = 0; d < 2; ++d)
-            mma32_x3_pair(dqt[d], x3_frag8(lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j, h, T()),
-                                           lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j + 1, h, T())), db8);
+            mma32_x3_pair(dqt[d], x3_frag8_pk(lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j, h, T()),
+                                              lds_perm_chunk(kt_l, 32 * d + col, b, 2 * j + 1, h, T())), db8);
         }
       } else {
 #pragma unroll
@@ -864,6 +897,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
     for (int ks = 0; ks < C::KS_D; ++ks) {
       kf[ks] = *(const Chunk*)(krow + (2 * ks + h) * 16);
       vf[ks] = *(const Chunk*)(vrow + (2 * ks + h) * 16);
+      if constexpr (X3 && sizeof(T) == 4) { kf[ks] = x3_unpack(kf[ks]); vf[ks] = x3_unpack(vf[ks]); }  // x3: packed (hi, lo) pairs
     }
   }
   // X3: the loop-invariant K / V fragments split once; the raw f32 copies die here
@@ -936,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
       if constexpr (X3f) {
 #pragma unroll
         for (int j = 0; j < C::KS_D / 2; ++j) {
-          mma32_x3_pair(st, x3_frag8(lds_chunk<T>(q_l, 32 * qa + col, 4 * j + h), lds_chunk<T>(q_l, 32 * qa + col, 4 * j + 2 + h)), kx[j]);
+          mma32_x3_pair(st, x3_frag8_pk(lds_chunk<T>(q_l, 32 * qa + col, 4 * j + h), lds_chunk<T>(q_l, 32 * qa + col, 4 * j + 2 + h)), kx[j]);
           mma32_x3_pair(dp, x3_frag8(lds_chunk<T>(do_l, 32 * qa + col, 4 * j + h), lds_chunk<T>(do_l, 32 * qa + col, 4 * j + 2 + h)), vx[j]);
         }
       } else {
@@ -962,8 +996,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
           for (int d = 0; d < 2; ++d) {
             mma32_x3_pair(dvt[d], x3_frag8(lds_perm_chunk(dot_l, 32 * d + col, qa, 2 * j, h, T()),
                                            lds_perm_chunk(dot_l, 32 * d + col, qa, 2 * j + 1, h, T())), pb);
-            mma32_x3_pair(dkt[d], x3_frag8(lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j, h, T()),
-                                           lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j + 1, h, T())), dsb);
+            mma32_x3_pair(dkt[d], x3_frag8_pk(lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j, h, T()),
+                                              lds_perm_chunk(qt_l, 32 * d + col, qa, 2 * j + 1, h, T())), dsb);
           }
         }
       } else {

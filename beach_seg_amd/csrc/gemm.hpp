@@ -52,6 +52,10 @@ struct GemmArgs {
   long o_gstride, o_off;
   const float* out_scale;  // EPI_UNPATCH: device scalar multiplied into the output (un-scaling of the fp16 gradient), or nullptr
   int x3;                  // f32 only: 1 = the three-term f16 split form of v3 (gemm_nt_kernel_v3<..., X3 = true>)
+  int pack_hl;             // f32, EPI_BIAS only (the QKV projection in x3 mode): every output element is stored as the pair
+                           // (f16 hi | f16 lo << 16), hi = f16(x), lo = f16(x - hi), in place of the float: the x3 attention
+                           // kernels then take q / k / v operand halves with two byte-permutes per chunk instead of
+                           // re-splitting every tile in every workgroup (attention.hpp x3_frag8_pk)
   float acc_scale;         // f32 only, 0 = off: the accumulator is multiplied by this power of two before the epilogue (x3 mode:
                            // the Linear weights are stored multiplied by its inverse so that their f16 hi / lo parts are normal)
   int group_m;  // v3: row tiles per L2 group (0 = 4)
@@ -144,6 +148,19 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       }
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
         const long orow = (EPI == EPI_PLAIN && g.o_rpg) ? (long)(m / g.o_rpg) * g.o_gstride + g.o_off + m % g.o_rpg : m;
+        if constexpr (sizeof(T) == 4 && EPI == EPI_BIAS) {
+          if (g.pack_hl) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const f16_t hi = (f16_t)v[r];
+              pk[r] = __builtin_bit_cast(unsigned, f16x2{hi, (f16_t)(v[r] - (float)hi)});
+            }
+            *(u32x4*)((float*)g.out + orow * g.ldo + n) = pk;
+            continue;
+          }
+        }
         *(typename Traits<T>::Vec4*)((T*)g.out + orow * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       } else if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;

@@ -346,6 +346,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = ln_out; g.W = m->lw(l, 2); g.M = rows; g.N = 3 * D; g.K = D; g.lda = D;
       g.bias = (const float*)m->lw(l, 4); g.out = qkv; g.ldo = 3 * D;
+      if (sizeof(T) == 4 && m->c.gemm_x3) g.pack_hl = 1;  // q / k / v as (f16 hi, f16 lo) pairs for the x3 attention kernels
       gemm<T, A_PLAIN, EPI_BIAS>(m, g, st);
       CHECK_LAUNCH();
     }
