@@ -66,8 +66,30 @@ struct GemmArgs {
 // 16-bit outputs, N % 16 == 0: exchange register pairs between the four 16-lane rows (v_permlane16_swap) so every
 // lane owns 8 consecutive columns -> 16-byte stores, 64 contiguous bytes per output row per instruction (the
 // narrow path writes 32-byte segments and doubles the number of memory requests of the tile's store burst).
+// Prefetched aux operand of one 64 x 64 sub-tile (EPI_BIAS_RESID: the fp32 residual; EPI_GELU_BWD: the saved gelu' in T, in
+// the first half of each slot): a kernel with one wave per SIMD (v5) requests sub-tile q + 1's while it finishes sub-tile q,
+// so that only the first request of an output tile waits for memory with nothing else to do.
+template <typename T, int EPI>
+DEVI void gemm_epilogue_aux_load(const GemmArgs& g, f32x4 (&ax)[4][4], int mw, int nw, int frow, int fchunk) {
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int mc = min(mw + mi * 16 + frow, g.M - 1);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = min(nw + ni * 16 + 4 * fchunk, g.N - 4);
+      if constexpr (EPI == EPI_BIAS_RESID) {
+        ax[ni][mi] = *(const f32x4*)((const float*)g.aux + (long)mc * g.ldaux + n);
+      } else if constexpr (EPI == EPI_GELU_BWD) {
+        const f32x2 h = *(const f32x2*)((const T*)g.aux + (long)mc * g.ldaux + n);
+        ax[ni][mi] = f32x4{h[0], h[1], 0.f, 0.f};
+      }
+    }
+  }
+}
+
 template <typename T, int EPI, int NMI = 4>
-DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
+DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk,
+                               const f32x4 (*ax)[4] = nullptr) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
   for (int mi = 0; mi < NMI; ++mi) {
@@ -88,7 +110,8 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
         hi2[ni] = pack2<T>(dy[2], dy[3]);
         v = y;
       } else if (EPI == EPI_GELU_BWD) {
-        const typename Traits<T>::Vec4 hp = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)mc * g.ldaux + n);
+        typedef typename Traits<T>::Vec4 HV;
+        const HV hp = ax ? __builtin_bit_cast(HV, f32x2{ax[ni][mi][0], ax[ni][mi][1]}) : *(const HV*)((const T*)g.aux + (long)mc * g.ldaux + n);
         v = f32x4{v[0] * (float)hp[0], v[1] * (float)hp[1], v[2] * (float)hp[2], v[3] * (float)hp[3]};
       }
       lo[ni] = pack2<T>(v[0], v[1]);
@@ -123,11 +146,11 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
 }
 
 template <typename T, int EPI, int NMI = 4>
-DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk) {
+DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, const f32x4 (*ax)[4] = nullptr) {
   if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
-      gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk);
+      gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk, ax);
       return;
     }
   }
@@ -170,7 +193,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
           *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(dy[0], dy[1], dy[2], dy[3]);
         *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(y[0], y[1], y[2], y[3]);
       } else if (EPI == EPI_BIAS_RESID) {
-        const f32x4 r = *(const f32x4*)((const float*)g.aux + (long)m * g.ldaux + n);
+        const f32x4 r = ax ? ax[ni][mi] : *(const f32x4*)((const float*)g.aux + (long)m * g.ldaux + n);
         *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
       } else if (EPI == EPI_EMBED) {
         const int s = m / g.tokens, t = m % g.tokens;
@@ -185,7 +208,10 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         const long o = ((((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) << lg) + c;
         *(typename Traits<T>::Vec4*)((T*)g.out + o) = pack4<T>(v[0], v[1], v[2], v[3]);
       } else if (EPI == EPI_GELU_BWD) {
-        const typename Traits<T>::Vec4 h = *(const typename Traits<T>::Vec4*)((const T*)g.aux + (long)m * g.ldaux + n);
+        typedef typename Traits<T>::Vec4 HV;
+        HV h;
+        if constexpr (sizeof(T) == 2) h = ax ? __builtin_bit_cast(HV, f32x2{ax[ni][mi][0], ax[ni][mi][1]}) : *(const HV*)((const T*)g.aux + (long)m * g.ldaux + n);
+        else h = *(const HV*)((const T*)g.aux + (long)m * g.ldaux + n);
         *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) =
             pack4<T>(v[0] * to_f32(h[0]), v[1] * to_f32(h[1]), v[2] * to_f32(h[2]), v[3] * to_f32(h[3]));
       } else if (EPI == EPI_UNPATCH) {
@@ -702,6 +728,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 #endif
 }
 
+// MFMA on accumulators pinned in the accumulator half of the register file (v4 / v5 experiment kernels)
+DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, bf16_t) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
 #ifdef BSG_GEMM_V4  // experiment build only (-DBSG_GEMM_V4, then BSG_GEMM=4): measured level with v3, see DESIGN.md section 8
 // ------------------------------------------------------------------------------------------------------------
 // v4 (16-bit dtypes, plain rows, M and N multiples of 256): 256 x 256 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 8 x 8
@@ -716,12 +749,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 // staged loads reading ONE address (same instruction stream, no operand traffic) 1.70 -- the 64 KiB per K tile and CU
 // that a 256 x 256 tile pulls from L2 (10.6 TB/s chip-wide at 1.36 PFLOP/s), not instruction issue, is what both
 // kernels wait on.  Kept as an experiment; v3 stays the product kernel.
-DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, bf16_t) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v4(GemmArgs g) {
@@ -880,6 +907,209 @@ template <int AMODE> static inline bool gemm_v4_ok(const GemmArgs& g, size_t es)
 
 #endif  // BSG_GEMM_V4
 
+// ------------------------------------------------------------------------------------------------------------
+// v5 (16-bit dtypes, plain rows, M and N multiples of 256, an even number of K tiles): the v4 tile shape (four waves, 128 x 128
+// wave tiles, 256 accumulators pinned in the accumulator file) with the operand pipeline of a two-tiles-ahead LDS-DMA stream:
+// buffer_load ... lds through an SGPR descriptor (the K advance is two scalar adds, no vector address math), waited for with
+// COUNTED vmcnt one tile later; both k-steps' fragments of both operands live in registers (128 VGPRs), read a full phase
+// (64 MFMAs) ahead, so the MFMA stream never waits on LDS except at the four barriers of a K tile:
+//   #1 every wave has read all of tile kt's A     -> A pieces of tile kt+2 may overwrite it
+//   #2 ... all of tile kt's W                     -> W pieces of tile kt+2
+//   #3 tile kt+1's A pieces have landed (vmcnt)   -> A fragments (k-step 0) of tile kt+1
+//   #4 tile kt+1's W pieces have landed           -> W fragments (k-step 0) of tile kt+1
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+DEVI i32x4_t raw_buffer_desc(const char* base_uniform) {
+  const unsigned long v = (unsigned long)base_uniform;
+  i32x4_t d;
+  d[0] = (int)(unsigned)v; d[1] = (int)(unsigned)((v >> 32) & 0xffffu); d[2] = -1; d[3] = 0x00020000;
+  return d;
+}
+// one LDS-DMA piece: lane l's 16 bytes at desc.base + voff land at LDS byte lds_uniform + 16 l
+DEVI void dma16_buf(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_uniform), "v"(voff), "s"(desc) : "memory");
+}
+#ifdef BSG_V5_NT
+DEVI void dma16_buf_nt(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_uniform), "v"(voff), "s"(desc) : "memory");
+}
+#else
+DEVI void dma16_buf_nt(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) { dma16_buf(lds_uniform, voff, desc); }
+#endif
+template <int N> DEVI void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+constexpr int v5_find(const int (&tab)[8], int n) {
+  for (int i = 0; i < 8; ++i)
+    if (tab[i] == n) return i;
+  return -1;
+}
+// positions (index of the MFMA an action follows, 0..127 within a K tile)
+constexpr int V5_A1[8] = {0, 3, 5, 7, 9, 11, 13, 15};             // A fragments, k-step 1
+constexpr int V5_W1[8] = {24, 27, 30, 33, 36, 39, 41, 43};        // W fragments, k-step 1
+constexpr int V5_A0[8] = {68, 70, 72, 74, 76, 78, 80, 82};        // A fragments, k-step 0 of the next tile
+constexpr int V5_W0[8] = {105, 107, 109, 111, 113, 115, 117, 119};  // W fragments, k-step 0 of the next tile
+// (measured: the same pieces spread one per 5 / 8 MFMAs +0.3 %; bunched right behind barriers #1 / #2 -7 %)
+constexpr int V5_DA[8] = {22, 25, 28, 31, 34, 52, 55, 58};        // A pieces of tile kt + 2
+constexpr int V5_DW[8] = {61, 64, 84, 86, 88, 94, 99, 123};       // W pieces of tile kt + 2
+constexpr int V5_VMA = 18, V5_VMW = 15;  // pieces of this round issued before the waits at MFMA 66 / 103, plus the 8 / 0 of last round's that may still fly
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
+  static_assert(sizeof(T) == 2, "v5: 16-bit operands");
+  constexpr int BK = 64, BUF = 65536;  // per stage: A 256 x 128 B, then W 256 x 128 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8;
+  const int nwg = tiles_m * tiles_n;
+  const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fchunk = lane >> 4;
+  const unsigned base = lds_addr(smem);
+  // fragment rows: wm*128 + i*16 + frow (i*16 rows = +2048 B immediates); chunk (fchunk + 4 ks) ^ (row & 7), row & 7 = frow & 7
+  unsigned aA[2][2], aW[2][2];  // [stage][k-step]
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      aA[b][ks] = (base + b * BUF + (wm * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4)) ^ (ks * 64);
+      aW[b][ks] = (base + b * BUF + 32768 + (wn * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4)) ^ (ks * 64);
+    }
+  const int nk = g.K / BK;
+  // DMA piece i of this wave: rows wave*64 + i*8 + prow of the A (W) tile; lane (prow, pchunk) fetches source chunk
+  // pchunk ^ prow of its row, which lands at chunk position pchunk (source-side swizzle)
+  const int prow = lane >> 3, pchunk = lane & 7;
+  unsigned voA[8], voW[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    voA[i] = (unsigned)((i * 8 + prow) * (long)g.lda * sizeof(T)) + ((pchunk ^ prow) << 4);
+    voW[i] = (unsigned)((i * 8 + prow) * (long)g.K * sizeof(T)) + ((pchunk ^ prow) << 4);
+  }
+  const unsigned ldsA = __builtin_amdgcn_readfirstlane(base + wave * 64 * 128), ldsW = ldsA + 32768;
+
+  const int GM = g.group_m > 0 ? g.group_m : 4;
+  auto coords = [&](int vb, int& m0, int& n0) {
+    const int bid = xcd_remap(vb, nwg);
+    const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
+    const int gm = min(GM, tiles_m - grp * GM);
+    m0 = (grp * GM + rem % gm) << 8;
+    n0 = (rem / gm) << 8;
+  };
+  const char *pa = nullptr, *pw = nullptr;
+  int kload = 0;  // K tile the next DMA round fetches (clamped to the last one: past the end the stream re-loads it, unread)
+  auto dma_a = [&](auto ii, int stage) {
+    constexpr int I = decltype(ii)::value;
+    dma16_buf(ldsA + stage * BUF + I * 1024, voA[I], raw_buffer_desc(pa + (long)kload * 128));
+  };
+  auto dma_w = [&](auto ii, int stage) {
+    constexpr int I = decltype(ii)::value;
+    dma16_buf_nt(ldsW + stage * BUF + I * 1024, voW[I], raw_buffer_desc(pw + (long)kload * 128));
+  };
+  auto advance = [&]() { kload = min(kload + 1, nk - 1); };
+  // fill: K tiles 0 and 1 of output tile (m0, n0) requested into stages 0 and 1
+  auto fill = [&](int m0, int n0) {
+    pa = uniform_ptr((const char*)g.A + (long)(m0 + wave * 64) * g.lda * sizeof(T));
+    pw = uniform_ptr((const char*)g.W + (long)(n0 + wave * 64) * g.K * sizeof(T));
+    kload = 0;
+    static_for<0, 8>([&](auto i) { dma_a(i, 0); });
+    static_for<0, 8>([&](auto i) { dma_w(i, 0); });
+    advance();
+    static_for<0, 8>([&](auto i) { dma_a(i, 1); });
+    static_for<0, 8>([&](auto i) { dma_w(i, 1); });
+    advance();
+  };
+  bool primed = false;
+
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+    int m0, n0;
+    coords(vb, m0, n0);
+    f32x4 acc[8][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][8], fw[2][8];  // [k-step][row block]
+
+    if (!primed) {
+      fill(m0, n0);
+      vm_wait<16>();
+    } else {
+      vm_wait<0>();  // the fill went out before the previous tile's epilogue: behind its stores nothing is countable
+    }
+    __builtin_amdgcn_s_barrier();
+    static_for<0, 8>([&](auto r) { fa[0][decltype(r)::value] = lds_read16_nw<decltype(r)::value * 2048>(aA[0][0]); });
+    static_for<0, 8>([&](auto r) { fw[0][decltype(r)::value] = lds_read16_nw<decltype(r)::value * 2048>(aW[0][0]); });
+    lds_wait<0>();
+
+    auto ktile = [&](auto pp) {
+      constexpr int P = decltype(pp)::value;  // stage of tile kt; tile kt + 1 sits in stage P ^ 1, tile kt + 2 goes to stage P
+      static_for<0, 128>([&](auto nn) {
+        constexpr int n = decltype(nn)::value, ph = n >> 6, ni = (n & 63) >> 3, mi = n & 7;
+        mfma16_agpr(acc[ni][mi], fw[ph][ni], fa[ph][mi], T());
+        constexpr int ra1 = v5_find(V5_A1, n), rw1 = v5_find(V5_W1, n), ra0 = v5_find(V5_A0, n), rw0 = v5_find(V5_W0, n);
+        constexpr int da = v5_find(V5_DA, n), dw = v5_find(V5_DW, n);
+        if constexpr (ra1 >= 0) fa[1][ra1] = lds_read16_nw<ra1 * 2048>(aA[P][1]);
+        if constexpr (rw1 >= 0) fw[1][rw1] = lds_read16_nw<rw1 * 2048>(aW[P][1]);
+        if constexpr (ra0 >= 0) fa[0][ra0] = lds_read16_nw<ra0 * 2048>(aA[P ^ 1][0]);
+        if constexpr (rw0 >= 0) fw[0][rw0] = lds_read16_nw<rw0 * 2048>(aW[P ^ 1][0]);
+        if constexpr (da >= 0) dma_a(std::integral_constant<int, da>{}, P);
+        if constexpr (dw >= 0) dma_w(std::integral_constant<int, dw>{}, P);
+        if constexpr (n == 19 || n == 50) lds_wait<0>();
+        if constexpr (n == 20 || n == 51) __builtin_amdgcn_s_barrier();   // #1, #2
+        if constexpr (n == 66) vm_wait<V5_VMA>();                         // last round's 8 A pieces are in
+        if constexpr (n == 103) vm_wait<V5_VMW>();                        // all of last round's
+        if constexpr (n == 67 || n == 104) __builtin_amdgcn_s_barrier();  // #3, #4
+      });
+      advance();
+      lds_wait<0>();  // next tile's k-step-0 fragments are in before the loop edge (and before any register copy there)
+    };
+    constexpr bool kAux = EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
+    f32x4 ax[2][4][4];
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(std::integral_constant<int, 0>{});
+      ktile(std::integral_constant<int, 1>{});
+    }
+    vm_wait<0>();
+    // MFMA results settle before anything reads the accumulators (see v4)
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
+                   "+a"(acc[7][6]), "+a"(acc[7][7])
+                 :
+                 : "memory");
+    __builtin_amdgcn_s_barrier();  // no wave's fill DMA of the next output tile lands under another wave's last fragment reads
+#ifdef BSG_V5_PRIME  // measured: no gain (the primed start has to wait for the epilogue's store drain with vmcnt(0))
+    primed = vb + (int)gridDim.x < nwg;
+    if (primed) {  // the next output tile's first two K tiles travel under this tile's epilogue
+      int nm0, nn0;
+      coords(vb + gridDim.x, nm0, nn0);
+      fill(nm0, nn0);
+    }
+#endif
+    // (requesting sub-tile 0's aux under the last two K tiles instead: slower, dfc2 * gelu' 22.8 -> 30.3 ms per step)
+    if constexpr (kAux) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
+    static_for<0, 4>([&](auto qq) {
+      constexpr int q = decltype(qq)::value, qn = q >> 1, qm = q & 1;
+      if constexpr (kAux && q < 3)
+        gemm_epilogue_aux_load<T, EPI>(g, ax[(q + 1) & 1], m0 + wm * 128 + ((q + 1) & 1) * 64, n0 + wn * 128 + ((q + 1) >> 1) * 64, frow, fchunk);
+      f32x4 sub[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
+      gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk, kAux ? ax[q & 1] : nullptr);
+    });
+  }
+}
+
+// Where v5 is the default (BSG_GEMM unset or 5; 6 = every epilogue, 3 = never).  Same-box kernel trace of the B = 64 train step,
+// ms per step, v5 vs v3: plain dgrads 29.3 vs 30.7, residual epilogues (proj, fc2) 27.3 vs 28.1, decoder embed 9.2 vs 10.1; bias
+// (QKV) 16.7 vs 16.4, fc1 + GELU (two outputs) 27.9 vs 26.9, dfc2 * gelu' 23.3 vs 21.5 -- with one wave per SIMD nothing runs
+// under a wave's epilogue, so the epilogues that move the most bytes per tile stay with the eight-wave kernel.
+template <int EPI> constexpr bool gemm_v5_pick() { return EPI == EPI_PLAIN || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT; }
+template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
+  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M &&
+         (long)g.lda * 2 * 64 < (1L << 31) && (long)g.K * 2 * 64 < (1L << 31);
+}
+
 // the 224-row form is instantiated for the 16-bit GEMMs of the encoder blocks only (plain rows; the decoder GEMMs are whole
 // rounds on 256-row tiles already)
 // 224-row tiles when they turn a ragged number of rounds (of 256 workgroups) into a cheaper whole one: cost = rounds x rows.
@@ -907,13 +1137,18 @@ template <typename T, int AMODE, int EPI> constexpr bool gemm_tm224_built() {
 
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 3;
+  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 5;  // 5: v5 for the epilogues of gemm_v5_pick, else v3; 6: v5 wherever its addressing applies; 3: v3 only
   if (ver == 1) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
   } else if ((ver == 2 || g.N <= 192) && !(sizeof(T) == 4 && g.x3)) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
+  } else if ((ver == 6 || (ver == 5 && gemm_v5_pick<EPI>())) && gemm_v5_ok<AMODE>(g, sizeof(T))) {
+    if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN) {
+      const int tiles = (g.M / 256) * (g.N / 256);
+      hipLaunchKernelGGL((gemm_nt_kernel_v5<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);
+    }
 #ifdef BSG_GEMM_V4
   } else if (ver == 4 && gemm_v4_ok<AMODE>(g, sizeof(T))) {
     if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN) {
