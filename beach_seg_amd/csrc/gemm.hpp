@@ -89,7 +89,7 @@ DEVI void gemm_epilogue_aux_load(const GemmArgs& g, f32x4 (&ax)[4][4], int mw, i
 
 template <typename T, int EPI, int NMI = 4>
 DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk,
-                               const f32x4 (*ax)[4] = nullptr) {
+                               const f32x4 (*ax)[4] = nullptr, const f32x4* bv = nullptr) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #pragma unroll
   for (int mi = 0; mi < NMI; ++mi) {
@@ -101,7 +101,7 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
     for (int ni = 0; ni < 4; ++ni) {
       const int n = min(nw + ni * 16 + 4 * fchunk, g.N - 4);
       f32x4 v = acc[ni][mi];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT) v += *(const f32x4*)(g.bias + n);
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT) v += bv ? bv[ni] : *(const f32x4*)(g.bias + n);
       if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
@@ -146,11 +146,12 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
 }
 
 template <typename T, int EPI, int NMI = 4>
-DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, const f32x4 (*ax)[4] = nullptr) {
+DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, const f32x4 (*ax)[4] = nullptr,
+                        const f32x4* bv = nullptr) {  // bv: the sub-tile's four bias vectors (column blocks ni), loaded by the caller
   if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
-      gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk, ax);
+      gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk, ax, bv);
       return;
     }
   }
@@ -166,7 +167,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       if (EPI == EPI_NONE) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
       if constexpr (sizeof(T) == 4) { if (g.acc_scale != 0.f) v *= g.acc_scale; }
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
-        const f32x4 b = *(const f32x4*)(g.bias + n);
+        const f32x4 b = bv ? bv[ni] : *(const f32x4*)(g.bias + n);
         v += b;
       }
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
@@ -1028,6 +1029,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 fa[2][8], fw[2][8];  // [k-step][row block]
+    // the wave tile's eight bias vectors arrive under the K loop (inside the epilogue every re-load behind a store would
+    // wait for L2 with nothing else on the SIMD)
+    constexpr bool kBias = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT;
+    f32x4 bias8[8];
+    if constexpr (kBias) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bias8[i] = *(const f32x4*)(g.bias + min(n0 + wn * 128 + i * 16 + 4 * fchunk, g.N - 4));
+    }
 
     if (!primed) {
       fill(m0, n0);
@@ -1040,8 +1049,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     static_for<0, 8>([&](auto r) { fw[0][decltype(r)::value] = lds_read16_nw<decltype(r)::value * 2048>(aW[0][0]); });
     lds_wait<0>();
 
-    auto ktile = [&](auto pp) {
+    constexpr bool kAux = EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
+#ifdef BSG_V5_EARLY_RESID
+    constexpr bool kAuxEarly = kAux;
+#else
+    constexpr bool kAuxEarly = EPI == EPI_GELU_BWD;  // the fp32 residual (16 x 16-byte loads + their addresses in the MFMA stream): slower
+#endif
+    f32x4 ax[2][4][4];
+    // DMA: this K tile requests tile kt + 2 (false for the last two of an output tile); NEXT: it reads tile kt + 1's k-step-0
+    // fragments (false for the last one, which instead requests the first sub-tile's epilogue operand under its MFMAs)
+    auto ktile = [&](auto pp, auto dd, auto xx) {
       constexpr int P = decltype(pp)::value;  // stage of tile kt; tile kt + 1 sits in stage P ^ 1, tile kt + 2 goes to stage P
+      constexpr bool DMA = decltype(dd)::value, NEXT = decltype(xx)::value;
       static_for<0, 128>([&](auto nn) {
         constexpr int n = decltype(nn)::value, ph = n >> 6, ni = (n & 63) >> 3, mi = n & 7;
         mfma16_agpr(acc[ni][mi], fw[ph][ni], fa[ph][mi], T());
@@ -1049,26 +1068,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
         constexpr int da = v5_find(V5_DA, n), dw = v5_find(V5_DW, n);
         if constexpr (ra1 >= 0) fa[1][ra1] = lds_read16_nw<ra1 * 2048>(aA[P][1]);
         if constexpr (rw1 >= 0) fw[1][rw1] = lds_read16_nw<rw1 * 2048>(aW[P][1]);
-        if constexpr (ra0 >= 0) fa[0][ra0] = lds_read16_nw<ra0 * 2048>(aA[P ^ 1][0]);
-        if constexpr (rw0 >= 0) fw[0][rw0] = lds_read16_nw<rw0 * 2048>(aW[P ^ 1][0]);
-        if constexpr (da >= 0) dma_a(std::integral_constant<int, da>{}, P);
-        if constexpr (dw >= 0) dma_w(std::integral_constant<int, dw>{}, P);
-        if constexpr (n == 19 || n == 50) lds_wait<0>();
-        if constexpr (n == 20 || n == 51) __builtin_amdgcn_s_barrier();   // #1, #2
-        if constexpr (n == 66) vm_wait<V5_VMA>();                         // last round's 8 A pieces are in
-        if constexpr (n == 103) vm_wait<V5_VMW>();                        // all of last round's
-        if constexpr (n == 67 || n == 104) __builtin_amdgcn_s_barrier();  // #3, #4
+        if constexpr (NEXT && ra0 >= 0) fa[0][ra0] = lds_read16_nw<ra0 * 2048>(aA[P ^ 1][0]);
+        if constexpr (NEXT && rw0 >= 0) fw[0][rw0] = lds_read16_nw<rw0 * 2048>(aW[P ^ 1][0]);
+        if constexpr (DMA && da >= 0) dma_a(std::integral_constant<int, da>{}, P);
+        if constexpr (DMA && dw >= 0) dma_w(std::integral_constant<int, dw>{}, P);
+        if constexpr (n == 19 || n == 50) lds_wait<0>();                          // k-step-1 fragments are in (phase 2 uses them)
+        if constexpr (DMA && (n == 20 || n == 51)) __builtin_amdgcn_s_barrier();   // #1, #2
+        if constexpr (NEXT && n == 66) vm_wait<(DMA ? V5_VMA : 8)>();              // tile kt + 1's 8 A pieces are in
+        if constexpr (NEXT && n == 103) vm_wait<(DMA ? V5_VMW : 0)>();             // all of tile kt + 1
+        if constexpr (NEXT && (n == 67 || n == 104)) __builtin_amdgcn_s_barrier();  // #3, #4
+        if constexpr (!NEXT && kAuxEarly && n == 4) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
       });
-      advance();
+      if constexpr (DMA) advance();
       lds_wait<0>();  // next tile's k-step-0 fragments are in before the loop edge (and before any register copy there)
     };
-    constexpr bool kAux = EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
-    f32x4 ax[2][4][4];
-    for (int kt = 0; kt < nk; kt += 2) {
-      ktile(std::integral_constant<int, 0>{});
-      ktile(std::integral_constant<int, 1>{});
+    typedef std::true_type Yes;
+    typedef std::false_type No;
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, Yes{}, Yes{});
+      ktile(std::integral_constant<int, 1>{}, Yes{}, Yes{});
     }
-    vm_wait<0>();
+    ktile(std::integral_constant<int, 0>{}, No{}, Yes{});
+    ktile(std::integral_constant<int, 1>{}, No{}, No{});
     // MFMA results settle before anything reads the accumulators (see v4)
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
@@ -1076,6 +1097,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
                  :
                  : "memory");
     __builtin_amdgcn_s_barrier();  // no wave's fill DMA of the next output tile lands under another wave's last fragment reads
+    if constexpr (kAux && !kAuxEarly) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
 #ifdef BSG_V5_PRIME  // measured: no gain (the primed start has to wait for the epilogue's store drain with vmcnt(0))
     primed = vb + (int)gridDim.x < nwg;
     if (primed) {  // the next output tile's first two K tiles travel under this tile's epilogue
@@ -1084,27 +1106,55 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
       fill(nm0, nn0);
     }
 #endif
-    // (requesting sub-tile 0's aux under the last two K tiles instead: slower, dfc2 * gelu' 22.8 -> 30.3 ms per step)
-    if constexpr (kAux) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
-    static_for<0, 4>([&](auto qq) {
-      constexpr int q = decltype(qq)::value, qn = q >> 1, qm = q & 1;
-      if constexpr (kAux && q < 3)
-        gemm_epilogue_aux_load<T, EPI>(g, ax[(q + 1) & 1], m0 + wm * 128 + ((q + 1) & 1) * 64, n0 + wn * 128 + ((q + 1) >> 1) * 64, frow, fchunk);
-      f32x4 sub[4][4];
+    // plain / bias / GELU epilogues: the four 64 x 64 sub-tiles go through ONE copy of the epilogue code (a rolled loop; the
+    // accumulators are picked by a switch) -- unrolled, the GELU epilogue alone is 135 KB of instructions against a 64 KB
+    // instruction cache (same box, ms per step, rolled vs unrolled: QKV 14.0 vs 14.5, fc1 + GELU 25.2 vs 26.3, plain dgrads
+    // 28.4 vs 29.8).  The aux-operand epilogues keep the unrolled form: their double-buffered prefetch needs static register
+    // names (rolled two by two, the buffers went to scratch: 263 vs 29 ms), and the pixel-shuffle one measured 9.8 vs 9.1.
+    constexpr bool kRolled = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU;
+    if constexpr (kRolled) {
+#pragma nounroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 sub[4][4], bv[4];
+        static_for<0, 4>([&](auto qq) {
+          constexpr int Q = decltype(qq)::value;
+          if (q == Q) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
-      gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk, kAux ? ax[q & 1] : nullptr);
-    });
+              for (int j = 0; j < 4; ++j) sub[i][j] = acc[(Q >> 1) * 4 + i][(Q & 1) * 4 + j];
+              if constexpr (kBias) bv[i] = bias8[(Q >> 1) * 4 + i];
+            }
+          }
+        });
+        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + (q & 1) * 64, n0 + wn * 128 + (q >> 1) * 64, frow, fchunk, nullptr, kBias ? bv : nullptr);
+      }
+    } else {
+      static_for<0, 4>([&](auto qq) {
+        constexpr int q = decltype(qq)::value, qn = q >> 1, qm = q & 1;
+        if constexpr (kAux && q < 3)
+          gemm_epilogue_aux_load<T, EPI>(g, ax[(q + 1) & 1], m0 + wm * 128 + ((q + 1) & 1) * 64, n0 + wn * 128 + ((q + 1) >> 1) * 64, frow, fchunk);
+        f32x4 sub[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
+        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk, kAux ? ax[q & 1] : nullptr,
+                              kBias ? &bias8[qn * 4] : nullptr);
+      });
+    }
   }
 }
 
-// Where v5 is the default (BSG_GEMM unset or 5; 6 = every epilogue, 3 = never).  Same-box kernel trace of the B = 64 train step,
-// ms per step, v5 vs v3: plain dgrads 29.3 vs 30.7, residual epilogues (proj, fc2) 27.3 vs 28.1, decoder embed 9.2 vs 10.1; bias
-// (QKV) 16.7 vs 16.4, fc1 + GELU (two outputs) 27.9 vs 26.9, dfc2 * gelu' 23.3 vs 21.5 -- with one wave per SIMD nothing runs
-// under a wave's epilogue, so the epilogues that move the most bytes per tile stay with the eight-wave kernel.
-template <int EPI> constexpr bool gemm_v5_pick() { return EPI == EPI_PLAIN || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT; }
+// Where v5 is the default (BSG_GEMM unset or 5; 6 = every epilogue its addressing covers, 3 = never).  Same-box kernel trace of
+// the B = 64 train step, ms per step, v5 vs v3: QKV (bias) 14.3 vs 16.3, fc1 + GELU (two outputs) 25.2 vs 27.2, plain dgrads
+// 28.4 vs 31.1, decoder embed 9.1 vs 10.1, dfc2 * gelu' 21.4 vs 21.9; the fp32 residual epilogues (proj, fc2) 29.1 vs 28.4 stay
+// with the eight-wave kernel (with one wave per SIMD nothing runs under a wave's epilogue; what made v5 win the others: bias
+// vectors requested before the K loop, the aux operand of sub-tile q + 1 requested before sub-tile q is stored, the first one
+// under the last K tile, and one rolled copy of the epilogue code).
+template <int EPI> constexpr bool gemm_v5_pick() {
+  return EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT || EPI == EPI_GELU_BWD;
+}
 template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
   return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M &&
          (long)g.lda * 2 * 64 < (1L << 31) && (long)g.K * 2 * 64 < (1L << 31);
