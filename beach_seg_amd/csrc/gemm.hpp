@@ -105,7 +105,11 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
       if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float yy, dd; gelu_both_f(v[r], yy, dd); y[r] = yy; dy[r] = dd; }
+        for (int r = 0; r < 4; r += 2) {
+          f32x2 yy, dd;
+          gelu_both_pk(f32x2{v[r], v[r + 1]}, yy, dd);
+          y[r] = yy[0]; y[r + 1] = yy[1]; dy[r] = dd[0]; dy[r + 1] = dd[1];
+        }
         lo2[ni] = pack2<T>(dy[0], dy[1]);
         hi2[ni] = pack2<T>(dy[2], dy[3]);
         v = y;
@@ -189,7 +193,11 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       } else if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { float yy, dd; gelu_both_f(v[r], yy, dd); y[r] = yy; dy[r] = dd; }
+        for (int r = 0; r < 4; r += 2) {
+          f32x2 yy, dd;
+          gelu_both_pk(f32x2{v[r], v[r + 1]}, yy, dd);
+          y[r] = yy[0]; y[r + 1] = yy[1]; dy[r] = dd[0]; dy[r + 1] = dd[1];
+        }
         if (g.out2)
           *(typename Traits<T>::Vec4*)((T*)g.out2 + (long)m * g.ldo + n) = pack4<T>(dy[0], dy[1], dy[2], dy[3]);
         *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(y[0], y[1], y[2], y[3]);
@@ -908,6 +916,79 @@ template <int AMODE> static inline bool gemm_v4_ok(const GemmArgs& g, size_t es)
 
 #endif  // BSG_GEMM_V4
 
+// v5's fp32 residual epilogue (out = acc + bias + aux, fp32, usually in place): the generic path's arithmetic with the same
+// scalar addressing as gemm_epilogue_v5_wide -- the aux request of sub-tile q + 1 and the stores of sub-tile q then need no
+// address registers, and the two 64-register aux buffers + the sub-tile fit without the scratch traffic the generic form had.
+DEVI void gemm_v5_resid_load(const GemmArgs& g, f32x4 (&ax)[4][4], int mw, int nw, unsigned vo) {
+  const char* ab = (const char*)g.aux + ((long)mw * g.ldaux + nw) * 4;
+  const long rstep = 16L * g.ldaux * 4;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) ax[ni][mi] = *(const f32x4*)(ab + mi * rstep + ni * 64 + vo);
+}
+DEVI void gemm_v5_resid_store(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, unsigned vo, const f32x4* bv, const f32x4 (&ax)[4][4]) {
+  char* ob = (char*)g.out + ((long)mw * g.ldo + nw) * 4;
+  const long rstep = 16L * g.ldo * 4;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) *(f32x4*)(ob + mi * rstep + ni * 64 + vo) = (acc[ni][mi] + bv[ni]) + ax[ni][mi];
+}
+
+// v5's epilogue for the row-major 16-bit outputs (plain / bias / bias + GELU with the saved derivative / gradient x saved
+// gelu'): gemm_epilogue_wide16's arithmetic and store pattern (identical bits), minus everything a whole, in-range 256 x 256
+// tile does not need -- no bounds masks, and the address of a store is a wave-uniform pointer (tile, sub-tile, 16-row block:
+// scalar arithmetic) plus ONE per-lane 32-bit offset that is constant for the kernel (global_store saddr form), where the
+// generic path spends ~10 vector instructions and a masked branch per store.
+template <typename T, int EPI>
+DEVI void gemm_epilogue_v5_wide(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, unsigned vo, const f32x4* bv,
+                                const f32x4 (*ax)[4]) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  char* ob = (char*)g.out + ((long)mw * g.ldo + nw) * sizeof(T);
+  char* ob2 = (EPI == EPI_BIAS_GELU && g.out2) ? (char*)g.out2 + ((long)mw * g.ldo + nw) * sizeof(T) : nullptr;
+  const long rstep = 16L * g.ldo * sizeof(T);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    unsigned lo[4], hi[4], lo2[4], hi2[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      f32x4 v = acc[ni][mi];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += bv[ni];
+      if (EPI == EPI_BIAS_GELU) {
+        f32x4 y, dy;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          f32x2 yy, dd;
+          gelu_both_pk(f32x2{v[r], v[r + 1]}, yy, dd);
+          y[r] = yy[0]; y[r + 1] = yy[1]; dy[r] = dd[0]; dy[r + 1] = dd[1];
+        }
+        lo2[ni] = pack2<T>(dy[0], dy[1]);
+        hi2[ni] = pack2<T>(dy[2], dy[3]);
+        v = y;
+      } else if (EPI == EPI_GELU_BWD) {
+        typedef typename Traits<T>::Vec4 HV;
+        const HV hp = __builtin_bit_cast(HV, f32x2{ax[ni][mi][0], ax[ni][mi][1]});
+        v = f32x4{v[0] * (float)hp[0], v[1] * (float)hp[1], v[2] * (float)hp[2], v[3] * (float)hp[3]};
+      }
+      lo[ni] = pack2<T>(v[0], v[1]);
+      hi[ni] = pack2<T>(v[2], v[3]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int ia = 2 * pr, ib = 2 * pr + 1;
+      auto r0 = __builtin_amdgcn_permlane16_swap(lo[ia], lo[ib], false, false);
+      auto r1 = __builtin_amdgcn_permlane16_swap(hi[ia], hi[ib], false, false);
+      *(u32x4*)(ob + mi * rstep + pr * 64 + vo) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      if (EPI == EPI_BIAS_GELU) {
+        auto q0 = __builtin_amdgcn_permlane16_swap(lo2[ia], lo2[ib], false, false);
+        auto q1 = __builtin_amdgcn_permlane16_swap(hi2[ia], hi2[ib], false, false);
+        if (ob2) *(u32x4*)(ob2 + mi * rstep + pr * 64 + vo) = u32x4{q0[0], q1[0], q0[1], q1[1]};
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // v5 (16-bit dtypes, plain rows, M and N multiples of 256, an even number of K tiles): the v4 tile shape (four waves, 128 x 128
 // wave tiles, 256 accumulators pinned in the accumulator file) with the operand pipeline of a two-tiles-ahead LDS-DMA stream:
@@ -986,6 +1067,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     voW[i] = (unsigned)((i * 8 + prow) * (long)g.K * sizeof(T)) + ((pchunk ^ prow) << 4);
   }
   const unsigned ldsA = __builtin_amdgcn_readfirstlane(base + wave * 64 * 128), ldsW = ldsA + 32768;
+  // per-lane byte offset of the epilogue's 16-byte stores inside a 16-row block (after the lane-row exchange a lane owns 8
+  // consecutive columns: column block fchunk & 1, half fchunk >> 1)
+  const unsigned vo_out = (unsigned)((frow * (long)g.ldo + (fchunk & 1) * 16 + (fchunk >> 1) * 8) * sizeof(T));
+  const unsigned vo_r_out = (unsigned)((frow * (long)g.ldo + 4 * fchunk) * 4), vo_r_aux = (unsigned)((frow * (long)g.ldaux + 4 * fchunk) * 4);  // fp32 residual form
 
   const int GM = g.group_m > 0 ? g.group_m : 4;
   auto coords = [&](int vb, int& m0, int& n0) {
@@ -1019,8 +1104,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     advance();
   };
   bool primed = false;
+  // de-phasing experiment (BSG_GEMM_STAGGER = s): workgroup i starts (i & 3) * s * 8128 cycles late, so that the CUs' epilogue
+  // store bursts (HBM-write-bound when all 256 arrive together) fall under other CUs' K loops
+  if (g.stagger > 0)
+    for (int i = (blockIdx.x & 3) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
 
+#ifdef BSG_DIAG_STAMPS
+  const long long st_wg_start = __builtin_amdgcn_s_memtime(), st_wg_real = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+#ifdef BSG_DIAG_STAMPS
+    const long long st_tile_start = __builtin_amdgcn_s_memtime();
+#endif
     int m0, n0;
     coords(vb, m0, n0);
     f32x4 acc[8][8];  // [ni][mi]
@@ -1056,6 +1151,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     constexpr bool kAuxEarly = EPI == EPI_GELU_BWD;  // the fp32 residual (16 x 16-byte loads + their addresses in the MFMA stream): slower
 #endif
     f32x4 ax[2][4][4];
+    auto aux_load = [&](f32x4 (&a)[4][4], int mw, int nw) {
+      if constexpr (EPI == EPI_BIAS_RESID) gemm_v5_resid_load(g, a, mw, nw, vo_r_aux);
+      else gemm_epilogue_aux_load<T, EPI>(g, a, mw, nw, frow, fchunk);
+    };
     // DMA: this K tile requests tile kt + 2 (false for the last two of an output tile); NEXT: it reads tile kt + 1's k-step-0
     // fragments (false for the last one, which instead requests the first sub-tile's epilogue operand under its MFMAs)
     auto ktile = [&](auto pp, auto dd, auto xx) {
@@ -1077,7 +1176,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
         if constexpr (NEXT && n == 66) vm_wait<(DMA ? V5_VMA : 8)>();              // tile kt + 1's 8 A pieces are in
         if constexpr (NEXT && n == 103) vm_wait<(DMA ? V5_VMW : 0)>();             // all of tile kt + 1
         if constexpr (NEXT && (n == 67 || n == 104)) __builtin_amdgcn_s_barrier();  // #3, #4
-        if constexpr (!NEXT && kAuxEarly && n == 4) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
+        if constexpr (!NEXT && kAuxEarly && n == 4) aux_load(ax[0], m0 + wm * 128, n0 + wn * 128);
       });
       if constexpr (DMA) advance();
       lds_wait<0>();  // next tile's k-step-0 fragments are in before the loop edge (and before any register copy there)
@@ -1097,7 +1196,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
                  :
                  : "memory");
     __builtin_amdgcn_s_barrier();  // no wave's fill DMA of the next output tile lands under another wave's last fragment reads
-    if constexpr (kAux && !kAuxEarly) gemm_epilogue_aux_load<T, EPI>(g, ax[0], m0 + wm * 128, n0 + wn * 128, frow, fchunk);
+#ifdef BSG_DIAG_STAMPS
+    const long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
+    if constexpr (kAux && !kAuxEarly) aux_load(ax[0], m0 + wm * 128, n0 + wn * 128);
 #ifdef BSG_V5_PRIME  // measured: no gain (the primed start has to wait for the epilogue's store drain with vmcnt(0))
     primed = vb + (int)gridDim.x < nwg;
     if (primed) {  // the next output tile's first two K tiles travel under this tile's epilogue
@@ -1127,36 +1229,57 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
             }
           }
         });
-        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + (q & 1) * 64, n0 + wn * 128 + (q >> 1) * 64, frow, fchunk, nullptr, kBias ? bv : nullptr);
+        gemm_epilogue_v5_wide<T, EPI>(g, sub, m0 + wm * 128 + (q & 1) * 64, n0 + wn * 128 + (q >> 1) * 64, vo_out, bv, nullptr);
       }
     } else {
       static_for<0, 4>([&](auto qq) {
         constexpr int q = decltype(qq)::value, qn = q >> 1, qm = q & 1;
-        if constexpr (kAux && q < 3)
-          gemm_epilogue_aux_load<T, EPI>(g, ax[(q + 1) & 1], m0 + wm * 128 + ((q + 1) & 1) * 64, n0 + wn * 128 + ((q + 1) >> 1) * 64, frow, fchunk);
+        if constexpr (kAux && q < 3) aux_load(ax[(q + 1) & 1], m0 + wm * 128 + ((q + 1) & 1) * 64, n0 + wn * 128 + ((q + 1) >> 1) * 64);
         f32x4 sub[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
-        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk, kAux ? ax[q & 1] : nullptr,
-                              kBias ? &bias8[qn * 4] : nullptr);
+        if constexpr (EPI == EPI_GELU_BWD)
+          gemm_epilogue_v5_wide<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, vo_out, nullptr, ax[q & 1]);
+        else if constexpr (EPI == EPI_BIAS_RESID)
+          gemm_v5_resid_store(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, vo_r_out, &bias8[qn * 4], ax[q & 1]);
+        else
+          gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk, kAux ? ax[q & 1] : nullptr,
+                                kBias ? &bias8[qn * 4] : nullptr);
       });
     }
+#ifdef BSG_DIAG_STAMPS
+    {
+      const long long st_issued = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long st_done = __builtin_amdgcn_s_memtime();
+      if (vb == (int)blockIdx.x + (int)gridDim.x && tid == 0 && blockIdx.x < 256) {  // second tile of each workgroup (steady state)
+        bsg_stamps[blockIdx.x * 4 + 0] = st_loop_end - st_tile_start;
+        bsg_stamps[blockIdx.x * 4 + 1] = st_issued - st_loop_end;
+        bsg_stamps[blockIdx.x * 4 + 2] = st_done - st_issued;
+      }
+    }
+#endif
   }
+#ifdef BSG_DIAG_STAMPS
+  if (tid == 0 && blockIdx.x < 256)
+    bsg_stamps[blockIdx.x * 4 + 3] = (__builtin_amdgcn_s_memtime() - st_wg_start) * 1000 / max(1LL, (long long)(__builtin_amdgcn_s_memrealtime() - st_wg_real));
+#endif
 }
 
 // Where v5 is the default (BSG_GEMM unset or 5; 6 = every epilogue its addressing covers, 3 = never).  Same-box kernel trace of
-// the B = 64 train step, ms per step, v5 vs v3: QKV (bias) 14.3 vs 16.3, fc1 + GELU (two outputs) 25.2 vs 27.2, plain dgrads
-// 28.4 vs 31.1, decoder embed 9.1 vs 10.1, dfc2 * gelu' 21.4 vs 21.9; the fp32 residual epilogues (proj, fc2) 29.1 vs 28.4 stay
-// with the eight-wave kernel (with one wave per SIMD nothing runs under a wave's epilogue; what made v5 win the others: bias
-// vectors requested before the K loop, the aux operand of sub-tile q + 1 requested before sub-tile q is stored, the first one
-// under the last K tile, and one rolled copy of the epilogue code).
-template <int EPI> constexpr bool gemm_v5_pick() {
-  return EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT || EPI == EPI_GELU_BWD;
-}
+// the B = 64 train step, ms per step, v5 vs v3: QKV (bias) 14.5 vs 16.7, fc1 + GELU (two outputs) 24.5 vs 27.0, proj / fc2 +
+// fp32 residual 26.1 vs 28.3, plain dgrads 28.3 vs 31.0, dfc2 * gelu' 20.2 vs 21.7, decoder embed 9.2 vs 10.2; the two small
+// one-per-step epilogues (patch-embed side) measured 1.04 vs 0.97 and 0.27 vs 0.25 and stay with v3.  With one wave per SIMD
+// nothing runs under a wave's epilogue, so v5's first form lost the epilogue-heavy GEMMs; what turned them: bias vectors
+// requested before the K loop, the aux operand of sub-tile q + 1 requested before sub-tile q is stored (gelu': the first one
+// under the last K tile), one rolled copy of the epilogue code, scalar store addressing without bounds masks, and the GELU on
+// element pairs (a lone wave issues one vector instruction per 4 cycles whatever its width).
+template <int EPI> constexpr bool gemm_v5_pick() { return EPI != EPI_EMBED && EPI != EPI_UNPATCH && EPI != EPI_NONE; }
 template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
-  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M &&
+  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M && g.o_rpg == 0 &&
+         (long)g.ldo * 4 * 16 < (1L << 31) && (long)g.ldaux * 4 * 16 < (1L << 31) &&
          (long)g.lda * 2 * 64 < (1L << 31) && (long)g.K * 2 * 64 < (1L << 31);
 }
 
