@@ -757,7 +757,8 @@ DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
 // Measured (M 100,352, N 16,384, K 4,096, one box): v4 1.34 PFLOP/s, v3 1.36, hipBLASLt 1.58; v4 with every lane of the
 // staged loads reading ONE address (same instruction stream, no operand traffic) 1.70 -- the 64 KiB per K tile and CU
 // that a 256 x 256 tile pulls from L2 (10.6 TB/s chip-wide at 1.36 PFLOP/s), not instruction issue, is what both
-// kernels wait on.  Kept as an experiment; v3 stays the product kernel.
+// kernels wait on.  Kept as an experiment.  (Round 3: that inference was wrong -- v5 below reaches 1.5 PFLOP/s on the same tile
+// and traffic with a two-tiles-ahead LDS-DMA stream and fully prefetched fragments.)
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v4(GemmArgs g) {
