@@ -16,11 +16,14 @@ def rel(a, b):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1000, 192, 128), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256),
-                                   (16 * 1568, 1024, 256), (25000, 1024, 192), (16 * 1568, 768, 128)])
+                                   (16 * 1568, 1024, 256), (25000, 1024, 192), (16 * 1568, 768, 128), (8 * 1568, 2048, 512)])
 def test_gemm_nt_vs_torch(dtype, M, N, K):
-    """Every GEMM variant: v3 (256 x 256 persistent), v2 (N <= 192), ragged M / N edges, bias epilogue; the last three shapes
-    have a ragged second round of 256-row tiles (392 / 391 / 294 tiles), a ragged last row tile and a ragged last column tile
-    (they take the 224-row-tile form of v3 in the -DBSG_GEMM_TM224 experiment build)."""
+    """Every GEMM variant: v5 (16-bit dtypes, M and N multiples of 256, an even number of K tiles: (256, 256, 256)-class shapes,
+    (16 * 1568, 1024, 256) = 392 tiles in two persistent rounds, (16 * 1568, 768, 128) = only the two DMA-less last K tiles,
+    (8 * 1568, 2048, 512)), v3 (256 x 256 persistent: f32, ragged or odd-K-tile shapes), v2 (N <= 192), ragged M / N edges, bias
+    epilogue; (16 * 1568, 1024, 256), (25000, 1024, 192) and (16 * 1568, 768, 128) have a ragged second round of 256-row tiles,
+    a ragged last row tile and a ragged last column tile.  v5 against v3 bit for bit, every epilogue, forward and backward:
+    `test_gpu_fullsize.py::test_vit_large_b64_engine_call_sequence_matches_b1_bit_for_bit` (B = 64 runs v5, B = 1 v3)."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(dtype)
     w = (torch.rand(N, K, device=DEV, generator=g) * 2 - 1).to(dtype)
