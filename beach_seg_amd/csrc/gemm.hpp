@@ -741,6 +741,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
 DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, bf16_t) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// an output tile's very last MFMA carries the settling nops in the SAME asm statement: nothing hipcc schedules can then land
+// between it and them (the seven MFMAs before it finish under it)
+DEVI void mfma16_agpr_settle(f32x4& acc, const f32x4& a, const f32x4& b, bf16_t) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+}
+DEVI void mfma16_agpr_settle(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+}
 DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
@@ -1163,7 +1171,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
       constexpr bool DMA = decltype(dd)::value, NEXT = decltype(xx)::value;
       static_for<0, 128>([&](auto nn) {
         constexpr int n = decltype(nn)::value, ph = n >> 6, ni = (n & 63) >> 3, mi = n & 7;
-        mfma16_agpr(acc[ni][mi], fw[ph][ni], fa[ph][mi], T());
+        if constexpr (!NEXT && n == 127) mfma16_agpr_settle(acc[ni][mi], fw[ph][ni], fa[ph][mi], T());
+        else mfma16_agpr(acc[ni][mi], fw[ph][ni], fa[ph][mi], T());
         constexpr int ra1 = v5_find(V5_A1, n), rw1 = v5_find(V5_W1, n), ra0 = v5_find(V5_A0, n), rw0 = v5_find(V5_W0, n);
         constexpr int da = v5_find(V5_DA, n), dw = v5_find(V5_DW, n);
         if constexpr (ra1 >= 0) fa[1][ra1] = lds_read16_nw<ra1 * 2048>(aA[P][1]);
@@ -1269,7 +1278,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
 #endif
 }
 
-// Where v5 is the default (BSG_GEMM unset or 5; 6 = every epilogue its addressing covers, 3 = never).  Same-box kernel trace of
+// Where v5 is the default (BSG_GEMM unset or 5; 3 = never).  Same-box kernel trace of
 // the B = 64 train step, ms per step, v5 vs v3: QKV (bias) 14.5 vs 16.7, fc1 + GELU (two outputs) 24.5 vs 27.0, proj / fc2 +
 // fp32 residual 26.1 vs 28.3, plain dgrads 28.3 vs 31.0, dfc2 * gelu' 20.2 vs 21.7, decoder embed 9.2 vs 10.2; the two small
 // one-per-step epilogues (patch-embed side) measured 1.04 vs 0.97 and 0.27 vs 0.25 and stay with v3.  With one wave per SIMD
@@ -1277,6 +1286,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
 // requested before the K loop, the aux operand of sub-tile q + 1 requested before sub-tile q is stored (gelu': the first one
 // under the last K tile), one rolled copy of the epilogue code, scalar store addressing without bounds masks, and the GELU on
 // element pairs (a lone wave issues one vector instruction per 4 cycles whatever its width).
+// v5 is INSTANTIATED for these epilogues only: its MFMAs are asm statements hipcc cannot see through, and in the pixel-unshuffle
+// variant it scheduled accumulator reads between the last MFMA and the settling nops (tests/test_kernel_isa.py checks the
+// compiled code of every instance for that hazard).
 template <int EPI> constexpr bool gemm_v5_pick() { return EPI != EPI_EMBED && EPI != EPI_UNPATCH && EPI != EPI_NONE; }
 template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
   return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M && g.o_rpg == 0 &&
@@ -1311,15 +1323,15 @@ template <typename T, int AMODE, int EPI> constexpr bool gemm_tm224_built() {
 
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 5;  // 5: v5 for the epilogues of gemm_v5_pick, else v3; 6: v5 wherever its addressing applies; 3: v3 only
+  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 5;  // 5: v5 for the epilogues of gemm_v5_pick where its addressing applies, else v3; 3: v3 only
   if (ver == 1) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
   } else if ((ver == 2 || g.N <= 192) && !(sizeof(T) == 4 && g.x3)) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
-  } else if ((ver == 6 || (ver == 5 && gemm_v5_pick<EPI>())) && gemm_v5_ok<AMODE>(g, sizeof(T))) {
-    if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN) {
+  } else if (ver >= 5 && gemm_v5_pick<EPI>() && gemm_v5_ok<AMODE>(g, sizeof(T))) {
+    if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN && gemm_v5_pick<EPI>()) {
       const int tiles = (g.M / 256) * (g.N / 256);
       hipLaunchKernelGGL((gemm_nt_kernel_v5<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);
     }

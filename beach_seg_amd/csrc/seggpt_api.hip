@@ -153,7 +153,7 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
     static bool once224 = (allow_lds(gemm_nt_kernel_v3<T, AM, EPI, 224>, 131072), true);
     (void)once224;
   }
-  if constexpr (sizeof(T) == 2 && AM == A_PLAIN) {
+  if constexpr (sizeof(T) == 2 && AM == A_PLAIN && gemm_v5_pick<EPI>()) {
     static bool once5 = (allow_lds(gemm_nt_kernel_v5<T, EPI>, 131072), true);
     (void)once5;
   }
