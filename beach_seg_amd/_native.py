@@ -19,7 +19,7 @@ SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend", "bsg_decode_hf",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_op_gemm_epilogue", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend", "bsg_decode_hf",
     "bsg_op_attention", "bsg_op_attention_scratch_bytes", "bsg_tif_image", "bsg_train_aug", "bsg_train_aug_bwd",
     "bsg_confusion_update", "bsg_loss_fwd_bwd_ids", "bsg_mask_rgb_norm",
 )
@@ -86,6 +86,7 @@ def load():
     lib.bsg_profile_read.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     lib.bsg_profile_reset.argtypes = [vp]
     lib.bsg_op_gemm.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
+    lib.bsg_op_gemm_epilogue.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]
     lib.bsg_tif_image.argtypes = [vp, i, i, i, i, vp, vp, vp, vp]
     lib.bsg_train_aug.argtypes = [vp, i, i, i, vp, vp, vp, vp, vp, f3, f3, vp, vp, vp]
     lib.bsg_train_aug_bwd.argtypes = [vp, i, i, i, vp, vp, vp, vp, f3, vp, vp]

@@ -931,6 +931,19 @@ size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp) {
 
 }  // extern "C"
 template <typename T>
+static int op_gemm_epilogue_impl(hipStream_t st, int epilogue, int M, int N, int K, const void* A, const void* W, const float* bias,
+                                 const void* aux, void* out, void* out2) {
+  bsg_model dummy{};
+  GemmArgs g{};
+  g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.bias = bias; g.out = out; g.ldo = N; g.aux = aux; g.ldaux = N; g.out2 = out2;
+  if (epilogue == 1) gemm<T, A_PLAIN, EPI_BIAS_GELU>(&dummy, g, st);
+  else if (epilogue == 2) gemm<T, A_PLAIN, EPI_BIAS_RESID>(&dummy, g, st);
+  else gemm<T, A_PLAIN, EPI_GELU_BWD>(&dummy, g, st);
+  CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
 static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
                              const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
                              size_t scratch_bytes) {
@@ -989,6 +1002,18 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
 }
 
 extern "C" {
+int bsg_op_gemm_epilogue(void* stream, int dtype, int epilogue, int M, int N, int K, const void* A, const void* W, const float* bias,
+                         const void* aux, void* out, void* out2) {
+  if (!A || !W || !out) return fail("bsg_op_gemm_epilogue: null argument");
+  if (dtype != BSG_DTYPE_BF16 && dtype != BSG_DTYPE_F16) return fail("bsg_op_gemm_epilogue: dtype must be 1 (bf16) or 2 (f16)");
+  if (epilogue < 1 || epilogue > 3) return fail("bsg_op_gemm_epilogue: epilogue must be 1 (bias + GELU), 2 (bias + fp32 residual) or 3 (times saved gelu')");
+  if ((epilogue != 3 && !bias) || (epilogue != 1 && !aux)) return fail("bsg_op_gemm_epilogue: the epilogue's bias / aux operand is missing");
+  if (K % 64 || N % 16 || N <= 192) return fail("bsg_op_gemm_epilogue: K must be a multiple of 64, N of 16 and above 192");
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == BSG_DTYPE_BF16 ? op_gemm_epilogue_impl<bf16_t>(st, epilogue, M, N, K, A, W, bias, aux, out, out2)
+                                 : op_gemm_epilogue_impl<f16_t>(st, epilogue, M, N, K, A, W, bias, aux, out, out2);
+}
+
 int bsg_op_attention(void* stream, int dtype, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
                      const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
                      size_t scratch_bytes) {

@@ -318,6 +318,32 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, 
     return out
 
 
+def gemm_nt_epilogue(epilogue: str, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None,
+                     aux: torch.Tensor | None = None, save_grad: bool = True):
+    """The NT GEMM with one of the encoder blocks' fused epilogues (bf16 / f16 operands): "gelu" -> (gelu(a w^T + bias),
+    gelu'(...) or None); "residual" -> a w^T + bias + aux in float32 (a new tensor); "gelu_bwd" -> (a w^T) * aux."""
+    _need_gpu(a, w, bias, aux)
+    lib = N.load()
+    if a.dtype != w.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("a and w must both be bfloat16 or both float16")
+    code = {"gelu": 1, "residual": 2, "gelu_bwd": 3}[epilogue]
+    M, K = a.shape
+    n = w.shape[0]
+    out2 = None
+    if code == 2:
+        out = aux.to(torch.float32).clone().contiguous()  # in place on the copy: the way the residual stream is updated
+        auxp = out
+    else:
+        out = torch.empty((M, n), dtype=a.dtype, device=a.device)
+        auxp = aux.contiguous() if aux is not None else None
+        if code == 1 and save_grad:
+            out2 = torch.empty_like(out)
+    with torch.cuda.device(a.device):
+        N.check(lib.bsg_op_gemm_epilogue(_stream(), _DTYPE_CODE[a.dtype], code, M, n, K, _ptr(a.contiguous()), _ptr(w.contiguous()),
+                                         _ptr(bias), _ptr(auxp), _ptr(out), _ptr(out2)))
+    return (out, out2) if code == 1 else out
+
+
 def attention_scratch(S: int, nh: int, hp: int, device) -> torch.Tensor:
     return torch.zeros(N.load().bsg_op_attention_scratch_bytes(S, nh, hp), dtype=torch.uint8, device=device)
 

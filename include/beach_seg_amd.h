@@ -225,6 +225,14 @@ int bsg_confusion_update(void* stream, long n, int K, int ignore_index, const in
 int bsg_op_gemm(void* stream, int dtype, int M, int N, int K, const void* A, const void* W, const float* bias,
                 void* out);
 
+/* The same kernel with one of the fused epilogues of the encoder blocks (unit tests), T = bf16 or f16 (dtype 1 / 2), acc = A W^T:
+ *   epilogue 1: out T = gelu(acc + bias), out2 T = gelu'(acc + bias) (out2 may be NULL)   -- fc1, erf GELU (HF ACT2FN["gelu"])
+ *   epilogue 2: out f32 = acc + bias + aux f32 (out may alias aux)                         -- proj / fc2 into the fp32 residual stream
+ *   epilogue 3: out T = acc * aux T                                                        -- dfc2 times the saved gelu'
+ * aux / out / out2 row-major [M][N].  Shapes with M, N multiples of 256 and K of 128 take gemm_nt_kernel_v5, others v3. */
+int bsg_op_gemm_epilogue(void* stream, int dtype, int epilogue, int M, int N, int K, const void* A, const void* W, const float* bias,
+                         const void* aux, void* out, void* out2);
+
 /* The fused attention kernels on their own (unit tests and micro-benchmarks), T = bf16 or f16 (dtype 1 / 2): qkv T[S*N][3*nh*64] (q | k | v column
  * blocks, head h at columns h*64), N = hp*wp tokens per stream; rel_cat / rel_catT as in the weight table (slots 18 / 19);
  * `which` bit 0: forward -> out T[S*N][nh*64], lse2 f32[S][nh][hp*32]; bit 1: dQ (needs out, lse2 of a forward and dout

@@ -37,6 +37,38 @@ def test_gemm_nt_vs_torch(dtype, M, N, K):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 256), (8 * 1568, 1024, 128), (2048, 1024, 1024), (777, 1024, 256), (1000, 320, 128)])
+def test_gemm_fused_epilogues_vs_torch(dtype, M, N, K):
+    """fc1 (bias + erf GELU, with the saved derivative), proj / fc2 (bias + fp32 residual, in place) and dfc2 (times the saved
+    gelu') epilogues against float64 torch, on shapes that take `gemm_nt_kernel_v5` (the first three: M, N multiples of 256, 2 /
+    2 / 16 K tiles, one of them two persistent rounds) and on ragged ones that take v3.  The two kernels run the same epilogue
+    arithmetic, so the same tolerances hold: output rounding of the 16-bit results, ~1e-6 for the fp32 residual."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(dtype)
+    w = ((torch.rand(N, K, device=DEV, generator=g) * 2 - 1) * (3.0 / K ** 0.5)).to(dtype)  # pre-activations of a few units
+    b = torch.randn(N, device=DEV, generator=g)
+    acc = a.double() @ w.double().t()
+    x = acc + b.double()
+    eps = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    # bias + GELU and its derivative
+    y, dy = ops.gemm_nt_epilogue("gelu", a, w, b)
+    cdf = 0.5 * (1 + torch.erf(x / 2 ** 0.5))
+    pdf = torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    assert rel(y, x * cdf) < 1.5 * eps and rel(dy, cdf + x * pdf) < 1.5 * eps
+    y1, none = ops.gemm_nt_epilogue("gelu", a, w, b, save_grad=False)
+    assert none is None and torch.equal(y1, y)
+    # bias + fp32 residual
+    r = torch.randn(M, N, device=DEV, generator=g) * 3
+    out = ops.gemm_nt_epilogue("residual", a, w, b, aux=r)
+    assert out.dtype == torch.float32 and rel(out, x + r.double()) < 2e-6
+    # gradient times the saved derivative
+    h = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(dtype)
+    d = ops.gemm_nt_epilogue("gelu_bwd", a, w, aux=h)
+    assert rel(d, acc * h.double()) < 1.5 * eps
+    assert all(torch.isfinite(t.float()).all() for t in (y, dy, out, d))
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256), (25000, 1024, 192)])
 def test_gemm_x3_vs_exact(M, N, K):
     """`gemm_nt_kernel_v3<float, ..., X3>`: float32 operands as hi = f16(x), lo = f16(x - hi), three f16 MFMAs per exact-f32
