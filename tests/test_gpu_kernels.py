@@ -38,11 +38,11 @@ def test_gemm_nt_vs_torch(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,K", [(512, 768, 256), (8 * 1568, 1024, 128), (2048, 1024, 1024), (777, 1024, 256), (1000, 320, 128)])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 256), (8 * 1568, 1024, 128), (2048, 1024, 1024), (64 * 1536, 1024, 1024), (777, 1024, 256), (1000, 320, 128)])
 def test_gemm_fused_epilogues_vs_torch(dtype, M, N, K):
     """fc1 (bias + erf GELU, with the saved derivative), proj / fc2 (bias + fp32 residual, in place) and dfc2 (times the saved
-    gelu') epilogues against float64 torch, on shapes that take `gemm_nt_kernel_v5` (the first three: M, N multiples of 256, 2 /
-    2 / 16 K tiles, one of them two persistent rounds) and on ragged ones that take v3.  The two kernels run the same epilogue
+    gelu') epilogues against float64 torch, on shapes that take `gemm_nt_kernel_v5` (the first four: M, N multiples of 256, 2 /
+    2 / 16 / 16 K tiles, one of them two persistent rounds, one the six full rounds of the train step's N = 1024 GEMMs) and on ragged ones that take v3.  The two kernels run the same epilogue
     arithmetic, so the same tolerances hold: output rounding of the 16-bit results, ~1e-6 for the fp32 residual."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     a = (torch.rand(M, K, device=DEV, generator=g) * 2 - 1).to(dtype)
@@ -67,6 +67,11 @@ def test_gemm_fused_epilogues_vs_torch(dtype, M, N, K):
     d = ops.gemm_nt_epilogue("gelu_bwd", a, w, aux=h)
     assert rel(d, acc * h.double()) < 1.5 * eps
     assert all(torch.isfinite(t.float()).all() for t in (y, dy, out, d))
+    # run to run: the same launch gives the same bits (a variant of v5 whose epilogue spilled accumulators to scratch did not)
+    y2, dy2 = ops.gemm_nt_epilogue("gelu", a, w, b)
+    assert torch.equal(y2, y) and torch.equal(dy2, dy)
+    assert torch.equal(ops.gemm_nt_epilogue("residual", a, w, b, aux=r), out)
+    assert torch.equal(ops.gemm_nt_epilogue("gelu_bwd", a, w, aux=h), d)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256), (25000, 1024, 192)])
