@@ -93,4 +93,8 @@ def test_gemm_v5_accumulators_untouched_between_mfmas(tmp_path):
         assert not [t for t in loop if t.startswith("scratch_")], f"{head}: scratch traffic inside the K loop"
         assert not [t for t in loop if t.startswith("s_waitcnt") and "vmcnt(0)" in t], f"{head}: vmcnt(0) inside the K loop"
         assert sum(t.startswith("buffer_load_dwordx4") and "lds" in t for t in loop) == 32, f"{head}: LDS-DMA pieces per two K tiles"
+        # (3) the DMA asm statements set m0 without declaring it (the clobber costs ~50 instructions per kernel): nothing else in
+        #     the kernel may use m0
+        other = [t for t in txt if re.search(r"\bm0\b", t) and not t.startswith("s_mov_b32 m0,")]
+        assert not other, f"{head}: m0 used outside the LDS-DMA set-up: {other[:3]}"
     assert seen >= 10, f"only {seen} v5 kernels found"  # 2 dtypes x the epilogues of gemm_v5_pick
