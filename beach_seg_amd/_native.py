@@ -8,8 +8,17 @@ import ctypes as C
 import os
 from pathlib import Path
 
-_LIB_PATH = Path(os.environ.get("BSG_LIB", Path(__file__).resolve().parent / "libbsg_hip.so"))  # BSG_LIB: experiments
+_LIB_PATH = Path(__file__).resolve().parent / "libbsg_hip.so"
 _lib = None
+
+
+def use_library(path) -> None:
+    """A/B tooling only (tools/step_ab.sh, tools/attn_probe.py): bind another build of the library instead of the in-tree
+    one.  Must be called before the first `load()`; the product path never calls it and reads no environment variable."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise NativeError("use_library() after the library has been loaded")
+    _LIB_PATH = Path(path).resolve()
 
 BSG_DTYPE_F32, BSG_DTYPE_BF16, BSG_DTYPE_F16 = 0, 1, 2
 BSG_MAX_TAPS, BSG_GLOBAL_WEIGHTS, BSG_LAYER_WEIGHTS = 8, 16, 20

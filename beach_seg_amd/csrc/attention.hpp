@@ -99,6 +99,9 @@ DEVI f32x4 x3_unpack(const f32x4& c) {  // packed pairs -> the float values (hi 
   return v;
 }
 template <typename Ch> DEVI Ch x3_unpack(const Ch& x) { return x; }
+// "use" of a register value that emits nothing: pins the point where hipcc has to have waited for the load that produces it
+template <typename V> DEVI void reg_consume(const V& v) { asm volatile("" ::"v"(v)); }
+DEVI void reg_consume(const X3Frag8& f) { asm volatile("" ::"v"(f.hi), "v"(f.lo)); }
 DEVI void mma32_x3_pair(f32x16& acc, const X3Frag8& a, const X3Frag8& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
@@ -167,7 +170,7 @@ DEVI void dma_tile(char* lds_tile, int wave, int lane, RowSrc row_src) {
   for (int i = 0; i < IPW; ++i) {
     const int r = (wave * IPW + i) * RPI + lane / CPR, p = lane % CPR;
     const char* src = row_src(r) + ((p ^ swz<RB>(r)) << 4);
-    glds16(src, lds_tile + (wave * IPW + i) * 1024);
+    glds16_asm(src, lds_tile + (wave * IPW + i) * 1024);
   }
 }
 
@@ -191,7 +194,7 @@ template <typename T>
 DEVI void dma_tile_issue(char* lds_tile, int wave, const char* base, const unsigned (&off)[TileDma<T>::IPW]) {
   typedef TileDma<T> D;
 #pragma unroll
-  for (int i = 0; i < D::IPW; ++i) glds16(base + off[i], lds_tile + (wave * D::IPW + i) * 1024);
+  for (int i = 0; i < D::IPW; ++i) glds16_asm(base + off[i], lds_tile + (wave * D::IPW + i) * 1024);
 }
 
 template <typename T> DEVI typename Traits<T>::Chunk lds_chunk(const char* tile, int row, int chunk) {
@@ -475,6 +478,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) qx[ks] = qf[ks];
   }
+  // (the two row-bias scalars of the next tile stay ORDINARY loads: hipcc waits for them -- `vmcnt(0)`, i.e. for the next tile's
+  // DMA as well -- at the loop's bottom edge, a whole tile after the request.  As uncounted asm loads they were wrong: hipcc
+  // copied their destination registers at the loop edge, before the top-of-tile wait.)
   f32x2 rh_next = f32x2{relh_g[0], relh_g[npad]};
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
@@ -699,6 +705,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) { qx[ks] = qf[ks]; dox[ks] = dof[ks]; }
   }
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(qx) / sizeof(qx[0])); ++i) { reg_consume(qx[i]); reg_consume(dox[i]); }  // waits for the Q / dO loads stay out of the loop
+  reg_consume(lse);
   issue(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -835,6 +844,7 @@ struct AttnBwdKvArgs {
   void* dk; void* dv;  // T, row stride ld
   int S, nh, N, hp, wp;
   float scale;
+  int kr_begin, kr_count;  // attention_kv4.hpp only: the key rows [kr_begin, kr_begin + kr_count) this launch covers
 };
 
 // LDS-DMA of a ROWS x RB-byte tile by NW waves (1 KiB per wave-instruction), optional chunk swizzle.
@@ -847,7 +857,7 @@ DEVI void dma_rows(char* lds_tile, int wave, int lane, RowSrc row_src) {
     if (NI % NW == 0 || j < NI) {
       const int r = j * RPI + lane / CPR, p = lane % CPR;
       const char* src = row_src(r) + ((SWZ ? (p ^ swz<RB>(r)) : p) << 4);
-      glds16(src, lds_tile + j * 1024);
+      glds16_asm(src, lds_tile + j * 1024);
     }
   }
 }
@@ -864,8 +874,12 @@ template <typename T, bool TR, int QT = 64> struct DkvK {
 // same LDS-DMA stream as the Q / dO tiles instead of occupying 128 registers.
 // QT = queries per streamed tile (64 or 128): a tile costs one workgroup barrier + one DMA wait for all 8 waves, so the
 // 128-query form halves the synchronisations (112 KB of LDS for the two stages; 16-bit dtypes only).
-template <typename T, bool TR, int QT = 64, bool X3 = false>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
+// NW = waves per workgroup = key rows per workgroup.  8 (round 1): one workgroup per CU, two waves per SIMD that meet at the SAME
+// barrier every query tile, so both are in their MFMA phase, then both in their exp phase.  4 (round 4, 16-bit dtypes): two
+// independent workgroups per CU (launch bound of two waves per SIMD, 56 KB of LDS each at QT = 64) -- the two waves of a SIMD
+// belong to different workgroups, drift apart, and one's vector phase runs under the other's MFMAs.
+template <typename T, bool TR, int QT = 64, bool X3 = false, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   typedef typename Traits<T>::Chunk Chunk;
   typedef AttnK<T> C;
   typedef DkvK<T, TR, QT> K_;
@@ -876,9 +890,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
-  attn_block_ids((a.hp + 7) / 8, a.nh, a.S, bx, head, s);
+  attn_block_ids((a.hp + NW - 1) / NW, a.nh, a.S, bx, head, s);
   const int nt = (a.N + QT - 1) / QT;
-  const int kr0 = bx * 8;
+  const int kr0 = bx * NW;
   const bool wave_valid = kr0 + wave < a.hp;
   const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
   const long sh = (long)s * a.nh + head;
@@ -911,6 +925,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 #pragma unroll
     for (int ks = 0; ks < C::KS_D; ++ks) { kx[ks] = kf[ks]; vx[ks] = vf[ks]; }
   }
+  // consumed here, before the loop: hipcc then waits for the K / V loads NOW and not at their first use inside the loop, where
+  // its `s_waitcnt vmcnt(0)` would also wait for the (to hipcc invisible) LDS-DMA of the next query tile
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(kx) / sizeof(kx[0])); ++i) { reg_consume(kx[i]); reg_consume(vx[i]); }
   const float c2 = a.scale * 1.44269504088896340736f;
   const bool key_valid = col < a.wp;
   f32x16 dkt[2], dvt[2];
@@ -919,22 +937,22 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs a) {
 
   auto issue = [&](int t, int buf) {
     char* base = smem + buf * STAGE;
-    dma_rows<RB, QT, 8, true>(base, wave, lane, [&](int r) {
+    dma_rows<RB, QT, NW, true>(base, wave, lane, [&](int r) {
       return qbase + (long)min(t * QT + r, a.N - 1) * a.ld * sizeof(T);
     });
-    dma_rows<RB, QT, 8, true>(base + K_::TILE, wave, lane, [&](int r) {
+    dma_rows<RB, QT, NW, true>(base + K_::TILE, wave, lane, [&](int r) {
       return dobase + (long)min(t * QT + r, a.N - 1) * a.ldo * sizeof(T);
     });
     if constexpr (!TR) {
-      dma_rows<RB, 64, 8, true>(base + 2 * K_::TILE, wave, lane,
+      dma_rows<RB, 64, NW, true>(base + 2 * K_::TILE, wave, lane,
                                 [&](int r) { return qtbase + ((long)r * npad + t * 64) * sizeof(T); });
-      dma_rows<RB, 64, 8, true>(base + 3 * K_::TILE, wave, lane,
+      dma_rows<RB, 64, NW, true>(base + 3 * K_::TILE, wave, lane,
                                 [&](int r) { return dotbase + ((long)r * npad + t * 64) * sizeof(T); });
     }
-    dma_rows<QB, 32, 8, true>(base + NTILE * K_::TILE, wave, lane, [&](int r) {
+    dma_rows<QB, 32, NW, true>(base + NTILE * K_::TILE, wave, lane, [&](int r) {
       return (const char*)(a.relwT + (sh * 32 + r) * npad + t * QT);
     });
-    dma_rows<QB, 16, 8, false>(base + NTILE * K_::TILE + K_::RW, wave, lane, [&](int r) {
+    dma_rows<QB, 16, NW, false>(base + NTILE * K_::TILE + K_::RW, wave, lane, [&](int r) {
       const float* p = r == 0 ? a.lse2 + sh * npad
                      : r == 1 ? a.delta + sh * npad
                               : a.relhT + (sh * a.hp + min(kr0 + max(r - 2, 0), a.hp - 1)) * npad;

@@ -112,6 +112,19 @@ DEVI void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 DEVI void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same copy as an asm statement, for loops that prefetch the NEXT tile while they read the current one (round 4).  hipcc
+// tracks the builtin form as a pending LDS write and cannot tell the tile it lands in from the tile being read (one dynamic
+// LDS array): it puts `s_waitcnt vmcnt(0)` in front of the first LDS read behind the copy -- in every attention kernel that
+// was 60-190 instructions after the issue, i.e. each tile waited for the prefetch it had just requested (wait_any 0.31-0.41 of
+// the wave cycles, profiles/r3_pmc_summary.json).  The asm form is invisible to that bookkeeping; the caller waits with
+// wait_vm0() + a barrier before the tile is read, which the loops did anyway.  M0 (the LDS base of the copy) is saved and
+// restored inside the statement (hipcc does not preserve it around asm; guide section 5.7).
+DEVI void glds16_asm(const void* gptr, const void* lds_wave_base) {
+  const unsigned lds_uniform = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds_uniform) : "memory");
+}
 
 // ---- LDS reads the compiler does not count (software-pipelined fragment reads at one wave per SIMD: hipcc's own
 //      waits collapse to lgkmcnt(0) right behind the prefetch).  The caller owns the wait: `lds_wait<N>()` leaves the N
@@ -146,6 +159,13 @@ DEVI f32x4 global_load16_nw(const void* sbase, unsigned voff) {
   f32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
+}
+// the same with a wave-uniform base, a 32-bit per-lane byte offset (saddr form: no 64-bit per-lane address arithmetic) and the
+// LDS destination as a wave-uniform byte address (lds_addr() of the piece): nothing here costs a vector instruction
+DEVI void glds16_asm_s(const char* sbase_uniform, unsigned voff, unsigned lds_uniform) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase_uniform), "s"(lds_uniform) : "memory");
 }
 template <int OFF> DEVI void lds_write16_nw(unsigned addr, const f32x4& v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" ::"v"(addr), "v"(v), "i"(OFF) : "memory");

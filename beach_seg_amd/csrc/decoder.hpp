@@ -154,17 +154,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// 16-bit dtypes: persistent "column-strip walker".  One workgroup per CU (4 waves, the whole 160 KB of LDS) owns a work
-// item = (image, 32-pixel column strip, row range) and walks it top to bottom in steps of 8 output rows:
+// 16-bit dtypes: persistent "column-strip walker" (conv3x3_ring8_kernel below).  One workgroup per CU (the whole 160 KB of LDS)
+// owns a work item = (image, 32-pixel column strip, row range) and walks it top to bottom in steps of 8 output rows:
 //   * the 72 KB filter bank [co][tap][ci] is staged in LDS ONCE per workgroup (rows padded to 1168 B: the 16 filter
 //     rows of a W fragment read land on distinct bank quads), not re-read from L2 by every wave for every tap;
 //   * the input rows live in an 18-row LDS ring (row slot = row mod 18, 36-pixel slots, chunk-swizzled by pixel); the 8
 //     rows of the NEXT step arrive by LDS-DMA (zero page for pixels outside the image) while the MFMAs of the current
-//     step run, so every input row is fetched once per strip (the 2-row vertical halo overlap is gone) and the halo
-//     fill no longer serialises with the compute;
-//   * wave w computes rows 2w, 2w+1 of the step: 2 rows x 32 pixels x 64 channels = 16 accumulator tiles, every
-//     fragment read (4 A + 4 W per tap / k-step) feeds 16 MFMAs;
-//   * the wait for the DMA sits BEFORE the epilogue's stores (vmcnt counts stores too), the step ends in one barrier.
+//     step run, so every input row is fetched once per strip (no vertical halo overlap) and the halo fill does not
+//     serialise with the compute;
+//   * the wait for the DMA sits BEFORE the epilogue's stores (vmcnt counts stores too).
+// (Round 2's four-wave form of the walker -- one wave per SIMD, MFMA phase and epilogue one after the other -- was superseded
+// by the eight-wave anti-phase form in round 3 and removed in round 4: DESIGN.md section 8.)
 constexpr int CR_ROWS = 8, CR_RING = 18, CR_SLOT_PX = 36, CR_WROW = 1168;
 constexpr int CR_W_BYTES = 64 * CR_WROW, CR_RING_BYTES = CR_RING * CR_SLOT_PX * 128, CR_LDS = CR_W_BYTES + CR_RING_BYTES;
 __device__ __attribute__((aligned(256))) const unsigned char bsg_conv_zero_page[256] = {0};
@@ -176,212 +176,15 @@ struct ConvRingArgs {
   int batch;
 };
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, 1) void conv3x3_ring_kernel(ConvRingArgs ra) {
-  static_assert(sizeof(T) == 2, "ring kernel: 16-bit activations (128-byte pixels)");
-  typedef typename Traits<T>::Chunk Chunk;
-  const ConvArgs& a = ra.c;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wl = smem;                 // filter bank, [64 co] rows of CR_WROW bytes: [tap][ci]
-  char* ring = smem + CR_W_BYTES;  // [CR_RING][CR_SLOT_PX] pixels x 128 B
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int frow = lane & 15, fchunk = lane >> 4;
-
-  // ---- filter bank -> LDS (once)
-  for (int i = tid; i < 64 * 72; i += 256) {
-    const int co = i / 72, ch = i % 72;
-    *(Chunk*)(wl + co * CR_WROW + ch * 16) = *(const Chunk*)((const char*)a.w + ((long)co * 72 + ch) * 16);
-  }
-
-  const int strips = a.W / 32, steps_total = (a.H - ra.y_begin) / CR_ROWS;
-  const int items = ra.batch * strips * ra.nsplit;
-  const char* zero = (const char*)bsg_conv_zero_page;
-
-  // DMA of one input row into its ring slot: 5 instructions (4 x 8 pixels + pixels 32, 33 on lanes 0..15).  The per-lane
-  // column part of the source address is fixed per work item (col_off / col_ok), the row part is wave-uniform.
-  const int lp = lane >> 3, lq = lane & 7;
-  unsigned col_off[5];
-  bool col_ok[5];
-  auto issue_row = [&](const char* img, int row) {
-    const int slot = (row + CR_RING) % CR_RING;
-    const bool row_ok = row >= 0 && row < a.H;
-    const char* rp = img + (long)row * a.W * 128;
-#pragma unroll
-    for (int part = 0; part < 5; ++part) {
-      const char* src = (row_ok && col_ok[part]) ? rp + col_off[part] : zero + (lq << 4);
-      if (part < 4 || lane < 16) glds16(src, ring + (slot * CR_SLOT_PX + part * 8) * 128);
-    }
-  };
-
-  // per-lane constants of the fused epilogue (bias, LayerNorm affine, 1x1 head): loaded once per workgroup
-  f32x4 cb[4], cg[4], cbe[4], cw0[4], cw1[4], cw2[4];
-  if (MODE == CONV_FWD_FUSED) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int c0 = ni * 16 + 4 * fchunk;
-      cb[ni] = *(const f32x4*)(a.bias + c0);
-      cg[ni] = *(const f32x4*)(a.ln_g + c0);
-      cbe[ni] = *(const f32x4*)(a.ln_b + c0);
-      cw0[ni] = *(const f32x4*)(a.head_w + c0);
-      cw1[ni] = *(const f32x4*)(a.head_w + 64 + c0);
-      cw2[ni] = *(const f32x4*)(a.head_w + 128 + c0);
-    }
-  }
-  const float hb0 = MODE == CONV_FWD_FUSED ? a.head_b[0] : 0.f, hb1 = MODE == CONV_FWD_FUSED ? a.head_b[1] : 0.f,
-              hb2 = MODE == CONV_FWD_FUSED ? a.head_b[2] : 0.f;
-
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int part = item % ra.nsplit, t = item / ra.nsplit;
-    const int strip = t % strips, b = t / strips;
-    const int s0 = (int)((long)steps_total * part / ra.nsplit), s1 = (int)((long)steps_total * (part + 1) / ra.nsplit);
-    if (s1 <= s0) continue;
-    const int x0 = strip * 32;
-    const char* img = (const char*)a.in + (long)b * a.H * a.W * 128;
-#pragma unroll
-    for (int part = 0; part < 5; ++part) {
-      const int p = part * 8 + lp, x = x0 - 1 + p;
-      col_ok[part] = x >= 0 && x < a.W;
-      col_off[part] = (unsigned)(x * 128 + ((lq ^ (p & 7)) << 4));
-    }
-    __syncthreads();  // every wave is done with the ring of the previous item (and the filter bank is staged)
-    {  // rows y - 1 .. y + 8 of the first step: two per wave, the last two by waves 0 and 1
-      const int r0 = ra.y_begin + s0 * CR_ROWS - 1;
-      issue_row(img, r0 + 2 * wave);
-      issue_row(img, r0 + 2 * wave + 1);
-      if (wave < 2) issue_row(img, r0 + 8 + wave);
-    }
-    wait_vm0();
-    __syncthreads();
-
-    for (int st = s0; st < s1; ++st) {
-      const int y0 = ra.y_begin + st * CR_ROWS;
-      if (st + 1 < s1) {  // the next step's 8 new rows, two per wave
-        issue_row(img, y0 + CR_ROWS + 1 + 2 * wave);
-        issue_row(img, y0 + CR_ROWS + 2 + 2 * wave);
-      }
-      f32x4 acc[4][4];  // [ni][mi], mi = (row in wave) * 2 + x half
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // ring bases of the 4 input rows this wave touches: y0 + 2 wave - 1 + {0, 1, 2, 3}
-      int rbase[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rbase[i] = ((y0 + 2 * wave - 1 + i + CR_RING) % CR_RING) * (CR_SLOT_PX * 128);
-      // 18 (tap, k-step) iterations, software-pipelined: the 8 fragment reads of iteration it + 1 are issued BEFORE the 16
-      // MFMAs of iteration it (one wave per SIMD: nothing else hides the LDS latency), order pinned by sched_barrier.
-      f32x4 fa[2][4], fw[2][4];
-      const unsigned wl_a = lds_addr(wl) + frow * CR_WROW + fchunk * 16, ring_a = lds_addr(ring);
-      auto load_frags = [&](int it, f32x4 (&A)[4], f32x4 (&Wf)[4]) {
-        const int tap = it >> 1, ks = it & 1, dy = tap / 3, dx = tap - 3 * dy, c = fchunk + 4 * ks;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Wf[i] = lds_read16_nowait(wl_a + i * 16 * CR_WROW + tap * 128 + ks * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int p = (i & 1) * 16 + frow + dx;  // pixel inside the slot
-          A[i] = lds_read16_nowait(ring_a + rbase[(i >> 1) + dy] + p * 128 + ((c ^ (p & 7)) << 4));
-        }
-      };
-      load_frags(0, fa[0], fw[0]);
-#pragma unroll
-      for (int it = 0; it < 18; ++it) {
-        if (it + 1 < 18) {
-          load_frags(it + 1, fa[(it + 1) & 1], fw[(it + 1) & 1]);
-          lds_wait<8>();  // iteration it's 8 fragments are in; the 8 just issued stay in flight under the MFMAs
-        } else {
-          lds_wait<0>();
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            mma16(acc[ni][mi], __builtin_bit_cast(Chunk, fw[it & 1][ni]), __builtin_bit_cast(Chunk, fa[it & 1][mi]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      wait_vm0();  // this wave's share of the next rows has landed (and the previous step's stores have left)
-
-      // acc[ni][mi][r]: pixel (y0 + 2 wave + (mi >> 1), x0 + (mi & 1) * 16 + frow), channel ni*16 + 4*fchunk + r
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int y = y0 + 2 * wave + (mi >> 1), x = x0 + (mi & 1) * 16 + frow;
-        const long pix = ((long)b * a.H + y) * a.W + x;
-        f32x4 v[4];
-        float s = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          v[ni] = acc[ni][mi];
-          if (MODE == CONV_FWD_FUSED) {
-            v[ni] += cb[ni];
-            s += v[ni][0] + v[ni][1] + v[ni][2] + v[ni][3];
-          }
-        }
-        if (MODE == CONV_PLAIN || a.out) {
-          // exchange register pairs between the four 16-lane rows so that a lane owns 8 consecutive channels: 16-byte stores
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-          unsigned lo[4], hi[4];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            lo[ni] = pack2<T>(v[ni][0], v[ni][1]);
-            hi[ni] = pack2<T>(v[ni][2], v[ni][3]);
-          }
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const int ia = 2 * pr, ib = 2 * pr + 1;
-            auto r0 = __builtin_amdgcn_permlane16_swap(lo[ia], lo[ib], false, false);
-            auto r1 = __builtin_amdgcn_permlane16_swap(hi[ia], hi[ib], false, false);
-            const int ch = ((fchunk & 1) ? ib : ia) * 16 + (fchunk >> 1) * 8;
-            *(u32x4*)((T*)a.out + pix * 64 + ch) = u32x4{r0[0], r1[0], r0[1], r1[1]};
-          }
-        }
-        if (MODE == CONV_FWD_FUSED) {
-          // the 64 channels of a pixel live in the 4 lanes {frow, frow+16, frow+32, frow+48}
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
-          const float mean = s * (1.f / 64.f);
-          float q = 0.f;
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[ni][r] -= mean; q += v[ni][r] * v[ni][r]; }
-          q += __shfl_xor(q, 16, 64);
-          q += __shfl_xor(q, 32, 64);
-          const float rstd = rsqrtf(q * (1.f / 64.f) + a.eps);
-          float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float tt = gelu_f(v[ni][r] * rstd * cg[ni][r] + cbe[ni][r]);
-              o0 += tt * cw0[ni][r]; o1 += tt * cw1[ni][r]; o2 += tt * cw2[ni][r];
-            }
-          }
-          o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
-          o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
-          o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
-          if (fchunk == 0) {
-            const long hw = (long)a.H * a.W, base = (long)b * 3 * hw + (long)y * a.W + x;
-            a.pred[base] = o0 + hb0;
-            a.pred[base + hw] = o1 + hb1;
-            a.pred[base + 2 * hw] = o2 + hb2;
-          }
-        }
-      }
-      __syncthreads();  // all waves: next rows landed (each waited above), nobody still reads the rows the next DMA replaces
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// The same walker with EIGHT waves in two groups that run in ANTI-PHASE (round 3).  In the four-wave kernel every SIMD
-// holds one wave, so the 288-MFMA phase of a step (MFMA pipe busy, vector ALU idle) and its fused bias + LayerNorm + GELU +
-// 1x1-head epilogue (vector ALU busy -- SQ_ACTIVE_INST_VALU 0.52 of the kernel -- MFMA pipe idle) run one after the other:
-// mfma_busy 0.26.  Here a wave owns ONE row of the 8-row step (2 x 4 accumulator tiles, 144 MFMAs); group 0 (waves 0-3,
+// EIGHT waves in two groups that run in ANTI-PHASE (round 3).  With four waves (one per SIMD) the 288-MFMA phase of a step
+// (MFMA pipe busy, vector ALU idle) and its fused bias + LayerNorm + GELU + 1x1-head epilogue (vector ALU busy --
+// SQ_ACTIVE_INST_VALU 0.52 of the kernel -- MFMA pipe idle) ran one after the other: mfma_busy 0.26.  Here a wave owns ONE row of the 8-row step (2 x 4 accumulator tiles, 144 MFMAs); group 0 (waves 0-3,
 // rows 0-3) and group 1 (waves 4-7, rows 4-7) share the SIMDs pairwise and are held half a step apart by two barriers per
 // step: while one group is in its MFMA phase the other is in its epilogue, so the two pipes of a SIMD work at the same time:
 //   half-period 2k   : group 0 MFMA(step k)   | group 1 epilogue(step k-1)     [all waves: DMA of step k+1's 8 new rows]
 //   half-period 2k+1 : group 0 epilogue(k)    | group 1 MFMA(step k)
-// The ring is the four-wave kernel's (18 rows): the rows of step k+1 replace interior rows of step k-1, whose last reader
+// The ring has 18 rows: the rows of step k+1 replace interior rows of step k-1, whose last reader
 // (group 1's MFMA phase, half-period 2k-1) is a barrier behind the issue (start of half-period 2k).  Filter bank, ring image,
 // swizzles, DMA pieces and the epilogue arithmetic are unchanged.
 template <typename T, int MODE>

@@ -59,7 +59,6 @@ struct GemmArgs {
   float acc_scale;         // f32 only, 0 = off: the accumulator is multiplied by this power of two before the epilogue (x3 mode:
                            // the Linear weights are stored multiplied by its inverse so that their f16 hi / lo parts are normal)
   int group_m;  // v3: row tiles per L2 group (0 = 4)
-  int stagger;  // v3: de-phasing sleep per K tile in units of 64 cycles per 1/8 phase step (0 = off)
 };
 
 // ---- shared epilogue: acc[ni][mi][r] = C[mw + mi*16 + (lane&15)][nw + ni*16 + 4*(lane>>4) + r]
@@ -450,10 +449,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v2(GemmArgs g) {
 #ifdef BSG_DIAG_STAMPS
 __device__ long long bsg_stamps[256 * 4];
 #endif
-// TM = 224: the same kernel on 224-row tiles (wave rows of 112 = 64 + 48: the second accumulator half holds 3 instead of 4
-// row tiles, phases 2 / 3 run 12 MFMAs).  M = 64 x 1568 = 100,352 rows are 392 x 256 but 448 x 224, and 448 row tiles x
-// any number of column tiles is a multiple of 256 CUs / 4: every GEMM of the step becomes a whole number of rounds
-// (N = 1024: 1,568 tiles = 6.125 rounds -> 1,792 tiles = 7 rounds of 0.875; no thin last round, no 128^2 tail launch).
+// TM: rows of the output tile.  Only 256 is instantiated (a 224-row form -- whole rounds on 256 CUs for M = 100,352 -- was built in
+// round 3 and measured slower on every shape of the step: DESIGN.md section 8).
 // X3 (T = float only): "float32 at three f16 MFMAs".  Every f32 operand is used as hi = f16(x), lo = f16(x - hi) (22
 // significant bits; the products hi*hi + hi*lo + lo*hi are exact in the fp32 accumulator, lo*lo ~2^-22 is dropped): the
 // eight exact-f32 `v_mfma_f32_16x16x4_f32` of a K tile and accumulator tile (32 k-values, 8 x 32 cycles) become three
@@ -463,7 +460,7 @@ __device__ long long bsg_stamps[256 * 4];
 // f16 MFMA, which runs at half the rate on gfx950: 246 TFLOP/s against 117 for the exact kernel).
 template <typename T, int AMODE, int EPI, int TM = 256, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
-  static_assert(TM == 256 || TM == 224, "row tile: 256 or 224");
+  static_assert(TM == 256, "row tile: 256");
   static_assert(!X3 || sizeof(T) == 4, "the three-term f16 split is the float32 kernel's option");
   constexpr int WR = TM / 2;                 // rows per wave row: mh0 = 64, mh1 = WR - 64
   constexpr int MH1 = (WR - 64) / 16;        // 16-row tiles of the second half: 4 or 3
@@ -555,15 +552,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel_v3(GemmArgs g) {
       for (int j = 0; j < 4; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  // De-phase the CUs.  All blocks of the first dispatch wave start together and do identical work, so without
-  // this every CU reaches its store burst at the same moment and HBM alternates between idle and saturated
-  // (measured: the stores of a K=1024 tile cost 14 % of the kernel, all of it exposed).  Blocks of the first wave
-  // sleep a different eighth of one tile time; later blocks inherit the phase of the CU they land on.
-  if (g.stagger && vb == (int)blockIdx.x && blockIdx.x < 256 && gridDim.x > 512) {
-    const int phase = (blockIdx.x >> 3) & 7;
-    const int naps = (phase * nk * g.stagger) >> 7;  // g.stagger = cycles per K tile / 64 (host-tuned)
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   if (!primed) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) issue(q, 0, 0);
@@ -752,178 +740,6 @@ DEVI void mfma16_agpr_settle(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) 
 DEVI void mfma16_agpr(f32x4& acc, const f32x4& a, const f32x4& b, f16_t) {
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-#ifdef BSG_GEMM_V4  // experiment build only (-DBSG_GEMM_V4, then BSG_GEMM=4): measured level with v3, see DESIGN.md section 8
-// ------------------------------------------------------------------------------------------------------------
-// v4 (16-bit dtypes, plain rows, M and N multiples of 256): 256 x 256 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 8 x 8
-// accumulator tiles = 256 registers kept in the accumulator half of the register file (MFMAs issued through asm with an
-// "a"-class accumulator: hipcc then leaves them in place; with the builtin it shuffles ~250 registers between the two
-// halves every K tile).  One wave per SIMD: 32 fragment reads per K tile feed 128 MFMAs (v3: 24 per 64).  There is no
-// partner wave to hide loads behind, and an LDS-DMA instruction holds the issue port ~60 cycles (measured: the same loop
-// with LDS-DMA operands 1.17 PFLOP/s, without the 16 DMA issues per K tile 1.76), so operands are REGISTER-STAGED:
-// global_load_dwordx4 (SGPR base + lane offset, one tile ahead in 64 registers) -> ds_write_b128 into the other LDS
-// buffer, all through uncounted asm slipped into the gaps of the wave's own MFMA stream; two barriers per K tile.
-// Measured (M 100,352, N 16,384, K 4,096, one box): v4 1.34 PFLOP/s, v3 1.36, hipBLASLt 1.58; v4 with every lane of the
-// staged loads reading ONE address (same instruction stream, no operand traffic) 1.70 -- the 64 KiB per K tile and CU
-// that a 256 x 256 tile pulls from L2 (10.6 TB/s chip-wide at 1.36 PFLOP/s), not instruction issue, is what both
-// kernels wait on.  Kept as an experiment.  (Round 3: that inference was wrong -- v5 below reaches 1.5 PFLOP/s on the same tile
-// and traffic with a two-tiles-ahead LDS-DMA stream and fully prefetched fragments.)
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v4(GemmArgs g) {
-  static_assert(sizeof(T) == 2, "v4: 16-bit operands");
-  constexpr int BK = 64, BUF = 65536;  // A 256 x 128 B, then W 256 x 128 B
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = g.N >> 8, tiles_m = g.M >> 8;
-  const int nwg = tiles_m * tiles_n;
-  const int wm = wave >> 1, wn = wave & 1, frow = lane & 15, fchunk = lane >> 4;
-  const unsigned base = lds_addr(smem);
-  // fragment rows: wm*128 + i*16 + frow (i*16 rows = +2048 B immediates); chunk (fchunk + 4 ks) ^ (row & 7), row & 7 = frow & 7
-  const unsigned aA0 = base + (wm * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4), aA1 = aA0 ^ 64;
-  const unsigned aW0 = base + 32768 + (wn * 128 + frow) * 128 + ((fchunk ^ (frow & 7)) << 4), aW1 = aW0 ^ 64;
-  const int nk = g.K / BK;
-  // staging: instruction i of this wave covers rows wave*64 + i*8 + prow of the A tile (i < 8) / W tile (i >= 8); lane
-  // (prow, pchunk) loads source chunk pchunk ^ prow of its row and stores it at LDS chunk position pchunk (source-side swizzle)
-  const int prow = lane >> 3, pchunk = lane & 7;
-  const unsigned wA = base + (wave * 64 + prow) * 128 + pchunk * 16, wW = wA + 32768;
-  const unsigned voffA0 = (unsigned)(prow * g.lda * sizeof(T)) + ((pchunk ^ prow) << 4);
-  const unsigned voffW0 = (unsigned)(prow * (long)g.K * sizeof(T)) + ((pchunk ^ prow) << 4);
-
-  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
-    int bid = xcd_remap(vb, nwg);
-    const int GM = g.group_m > 0 ? g.group_m : 4;
-    const int gsz = GM * tiles_n, grp = bid / gsz, rem = bid - grp * gsz;
-    const int gm = min(GM, tiles_m - grp * GM);
-    const int tm = grp * GM + rem % gm, tn = rem / gm;
-    const int m0 = tm << 8, n0 = tn << 8;
-    const char* sb[16];  // SGPR bases of the 16 staged row groups (8 rows each): A rows m0 + wave*64 + 8 i, W rows n0 + wave*64 + 8 i
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sb[i] = uniform_ptr((const char*)g.A + (long)(m0 + wave * 64 + i * 8) * g.lda * sizeof(T));
-      sb[8 + i] = uniform_ptr((const char*)g.W + (long)(n0 + wave * 64 + i * 8) * g.K * sizeof(T));
-    }
-    f32x4 stage[16];
-    unsigned voffA = voffA0, voffW = voffW0;  // advance by 128 B per K tile
-    auto gload = [&](auto jj) {
-      constexpr int J = decltype(jj)::value;
-      stage[J] = global_load16_nw(sb[J], J < 8 ? voffA : voffW);
-    };
-    auto swrite = [&](auto jj, unsigned bo) {
-      constexpr int J = decltype(jj)::value;
-      if constexpr (J < 8) lds_write16_nw<J * 1024>(wA + bo, stage[J]);
-      else lds_write16_nw<(J - 8) * 1024>(wW + bo, stage[J]);
-    };
-    f32x4 acc[8][8];  // [ni][mi]
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 fa[2][8], fwx[2];
-    auto read_a = [&](auto rr, auto kk, unsigned bo) {  // A fragment row block R of k-step KS
-      constexpr int R = decltype(rr)::value, KS = decltype(kk)::value;
-      fa[KS][R] = lds_read16_nw<R * 2048>((KS ? aA1 : aA0) + bo);
-    };
-    auto read_w = [&](auto rr, auto kk, auto slot, unsigned bo) {  // W fragment row block R of k-step KS into fwx[SLOT]
-      constexpr int R = decltype(rr)::value, KS = decltype(kk)::value, S = decltype(slot)::value;
-      fwx[S] = lds_read16_nw<R * 2048>((KS ? aW1 : aW0) + bo);
-    };
-
-    // K offsets of the staged loads are clamped to the last tile: past the end of K the pipeline keeps running on a
-    // harmless re-load of tile nk - 1 (nothing reads it), so the loop body carries no "is there a next tile" branch.
-    const unsigned kmax = (unsigned)(nk - 1) * 128;
-    unsigned koff = 0;
-    auto advance = [&]() { koff = min(koff + 128u, kmax); voffA = voffA0 + koff; voffW = voffW0 + koff; };
-    __syncthreads();  // the previous tile's last fragment reads are done before this tile's first writes land
-    static_for<0, 16>([&](auto j) { gload(j); });
-    advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_for<0, 16>([&](auto j) { swrite(j, 0u); });
-    static_for<0, 16>([&](auto j) { gload(j); });
-    advance();
-    lds_wait<0>();
-    __builtin_amdgcn_s_barrier();
-    static_for<0, 8>([&](auto r) { read_a(r, I0{}, 0u); });
-    read_w(I0{}, I0{}, I0{}, 0u);
-
-    // Invariant at the top of K tile kt: LDS buffer kt & 1 holds tile kt; `stage` holds tile kt + 1 (in flight); fa[0] = A
-    // fragments (kt, k-step 0); fwx[0] = W fragment (kt, k-step 0, row block 0).  LDS operations are waited for with
-    // COUNTED lgkmcnt: at a row block's start only its own W fragment (issued one row block earlier) must be back, the
-    // younger prefetches stay in flight.
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned bo = (kt & 1) * BUF, bn = bo ^ BUF;
-      // ---- phase 1: k-step 0.  Row blocks 0-3 also fetch the A fragments of k-step 1 (two each).
-      static_for<0, 8>([&](auto nn) {
-        constexpr int ni = decltype(nn)::value;
-        if constexpr (ni >= 1 && ni <= 4) lds_wait<2>(); else lds_wait<0>();
-        if constexpr (ni < 7) read_w(std::integral_constant<int, ni + 1>{}, I0{}, std::integral_constant<int, (ni + 1) & 1>{}, bo);
-        else read_w(I0{}, I1{}, I0{}, bo);  // first W fragment of k-step 1
-        static_for<0, 8>([&](auto mm) {
-          constexpr int mi = decltype(mm)::value;
-          mfma16_agpr(acc[ni][mi], fwx[ni & 1], fa[0][mi], T());
-          if constexpr (ni < 4 && (mi == 1 || mi == 5)) read_a(std::integral_constant<int, ni * 2 + (mi == 5)>{}, I1{}, bo);
-        });
-      });
-      // ---- phase 2: k-step 1.  Row blocks 0-3: the staged tile goes to the other LDS buffer (a store in every even MFMA
-      //      gap, the same register re-loaded two tiles ahead in the odd gap behind it); row block 4: barrier; row blocks
-      //      4-5: A fragments of the next tile's k-step 0.
-      static_for<0, 8>([&](auto nn) {
-        constexpr int ni = decltype(nn)::value;
-        if constexpr (ni >= 1 && ni <= 3) lds_wait<4>();
-        else if constexpr (ni == 5 || ni == 6) lds_wait<4>();
-        else lds_wait<0>();
-        if constexpr (ni == 0) __builtin_amdgcn_s_barrier();  // every wave is done reading buffer bn (tile kt - 1)
-        if constexpr (ni == 4) __builtin_amdgcn_s_barrier();  // tile kt + 1 is complete in bn
-        if constexpr (ni < 7) read_w(std::integral_constant<int, ni + 1>{}, I1{}, std::integral_constant<int, (ni + 1) & 1>{}, bo);
-        else read_w(I0{}, I0{}, I0{}, bn);  // first W fragment of the next tile
-        static_for<0, 8>([&](auto mm) {
-          constexpr int mi = decltype(mm)::value;
-          mfma16_agpr(acc[ni][mi], fwx[ni & 1], fa[1][mi], T());
-          if constexpr (ni < 4) {
-            constexpr int J = ni * 4 + mi / 2;
-            if constexpr ((mi & 1) == 0) {
-              // load J is the oldest of the 16 staged loads in flight (16 - J of the previous round, J re-issued in this one)
-              asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-              swrite(std::integral_constant<int, J>{}, bn);
-            } else {
-              gload(std::integral_constant<int, J>{});
-            }
-          }
-          if constexpr ((ni == 4 || ni == 5) && mi < 4) read_a(std::integral_constant<int, (ni - 4) * 4 + mi>{}, I0{}, bn);
-        });
-      });
-      advance();
-    }
-    // MFMA results settle before anything reads the accumulators: hipcc does not know the asm statements are MFMAs and
-    // would read (spill) the last tile's registers straight behind them -- the nops carry the last row block as operands
-    asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
-                   "+a"(acc[7][6]), "+a"(acc[7][7])
-                 :
-                 : "memory");
-#pragma unroll
-    for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-      for (int qm = 0; qm < 2; ++qm) {
-        f32x4 sub[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sub[i][j] = acc[qn * 4 + i][qm * 4 + j];
-        gemm_epilogue<T, EPI>(g, sub, m0 + wm * 128 + qm * 64, n0 + wn * 128 + qn * 64, frow, fchunk);
-      }
-  }
-}
-
-// v4 takes a GEMM when its addressing is the plain one the staged loads assume
-template <int AMODE> static inline bool gemm_v4_ok(const GemmArgs& g, size_t es) {
-  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 64 == 0 && g.a_rpg >= g.M &&
-         (long)g.lda * 2 * 8 < (1L << 31) && (long)g.K * 2 * 8 < (1L << 31);
-}
-
-#endif  // BSG_GEMM_V4
 
 // v5's fp32 residual epilogue (out = acc + bias + aux, fp32, usually in place): the generic path's arithmetic with the same
 // scalar addressing as gemm_epilogue_v5_wide -- the aux request of sub-tile q + 1 and the stores of sub-tile q then need no
@@ -1019,13 +835,6 @@ DEVI i32x4_t raw_buffer_desc(const char* base_uniform) {
 DEVI void dma16_buf(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_uniform), "v"(voff), "s"(desc) : "memory");
 }
-#ifdef BSG_V5_NT
-DEVI void dma16_buf_nt(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen nt lds" ::"s"(lds_uniform), "v"(voff), "s"(desc) : "memory");
-}
-#else
-DEVI void dma16_buf_nt(unsigned lds_uniform, unsigned voff, const i32x4_t& desc) { dma16_buf(lds_uniform, voff, desc); }
-#endif
 template <int N> DEVI void vm_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -1097,7 +906,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
   };
   auto dma_w = [&](auto ii, int stage) {
     constexpr int I = decltype(ii)::value;
-    dma16_buf_nt(ldsW + stage * BUF + I * 1024, voW[I], raw_buffer_desc(pw + (long)kload * 128));
+    dma16_buf(ldsW + stage * BUF + I * 1024, voW[I], raw_buffer_desc(pw + (long)kload * 128));
   };
   auto advance = [&]() { kload = min(kload + 1, nk - 1); };
   // fill: K tiles 0 and 1 of output tile (m0, n0) requested into stages 0 and 1
@@ -1113,11 +922,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     advance();
   };
   bool primed = false;
-  // de-phasing experiment (BSG_GEMM_STAGGER = s): workgroup i starts (i & 3) * s * 8128 cycles late, so that the CUs' epilogue
-  // store bursts (HBM-write-bound when all 256 arrive together) fall under other CUs' K loops
-  if (g.stagger > 0)
-    for (int i = (blockIdx.x & 3) * g.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
-
 #ifdef BSG_DIAG_STAMPS
   const long long st_wg_start = __builtin_amdgcn_s_memtime(), st_wg_real = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1154,11 +958,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     lds_wait<0>();
 
     constexpr bool kAux = EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
-#ifdef BSG_V5_EARLY_RESID
-    constexpr bool kAuxEarly = kAux;
-#else
     constexpr bool kAuxEarly = EPI == EPI_GELU_BWD;  // the fp32 residual (16 x 16-byte loads + their addresses in the MFMA stream): slower
-#endif
     f32x4 ax[2][4][4];
     auto aux_load = [&](f32x4 (&a)[4][4], int mw, int nw) {
       if constexpr (EPI == EPI_BIAS_RESID) gemm_v5_resid_load(g, a, mw, nw, vo_r_aux);
@@ -1210,14 +1010,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     const long long st_loop_end = __builtin_amdgcn_s_memtime();
 #endif
     if constexpr (kAux && !kAuxEarly) aux_load(ax[0], m0 + wm * 128, n0 + wn * 128);
-#ifdef BSG_V5_PRIME  // measured: no gain (the primed start has to wait for the epilogue's store drain with vmcnt(0))
-    primed = vb + (int)gridDim.x < nwg;
-    if (primed) {  // the next output tile's first two K tiles travel under this tile's epilogue
-      int nm0, nn0;
-      coords(vb + gridDim.x, nm0, nn0);
-      fill(nm0, nn0);
-    }
-#endif
     // plain / bias / GELU epilogues: the four 64 x 64 sub-tiles go through ONE copy of the epilogue code (a rolled loop; the
     // accumulators are picked by a switch) -- unrolled, the GELU epilogue alone is 135 KB of instructions against a 64 KB
     // instruction cache (same box, ms per step, rolled vs unrolled: QKV 14.0 vs 14.5, fc1 + GELU 25.2 vs 26.3, plain dgrads
@@ -1296,38 +1088,20 @@ template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es)
          (long)g.lda * 2 * 64 < (1L << 31) && (long)g.K * 2 * 64 < (1L << 31);
 }
 
-// the 224-row form is instantiated for the 16-bit GEMMs of the encoder blocks only (plain rows; the decoder GEMMs are whole
-// rounds on 256-row tiles already)
-// 224-row tiles when they turn a ragged number of rounds (of 256 workgroups) into a cheaper whole one: cost = rounds x rows.
-// MEASURED (round 3, one box, TFLOP/s 256-row with the 128^2 tail launch vs 224-row): M 100,352 x N 1024 x K 1024 813 vs 806,
-// K 4096 1157 vs 1121, K 3072 1186 vs 1146; N 3072 x K 1024 1088 vs 1023; N 4096 1101 vs 1044; whole step 283.3 vs 288.9 ms.
-// 12.5 % fewer MFMAs per K tile shorten the K tile by ~3 % only -- the loop's period is set by the partner wave's load
-// segment (LDS-DMA issue + fragment reads + two barriers per phase), not by the MFMA cluster -- so 7 rounds of "0.875"
-// tiles cost 7 x 0.97 against 6 + the tail's ~0.6.  Kept behind -DBSG_GEMM_TM224 as an experiment.
-static inline bool gemm_pick_224(const GemmArgs& g) {
-  static const int tm_env = getenv("BSG_GEMM_TM") ? atoi(getenv("BSG_GEMM_TM")) : 0;  // 256 / 224 force (A/B runs)
-  if (tm_env) return tm_env == 224;
-  if (g.N <= 192) return false;
-  const long tn = (g.N + 255) / 256, tiles = (long)((g.M + 255) / 256) * tn, tiles224 = (long)((g.M + 223) / 224) * tn;
-  const long r256 = (tiles + 255) / 256, r224 = (tiles224 + 255) / 256;
-  return tiles > 256 && tiles % 256 != 0 && r224 * 224 < r256 * 256;
-}
-template <typename T, int AMODE, int EPI> constexpr bool gemm_tm224_built() {
-#ifdef BSG_GEMM_TM224  // experiment build only: measured SLOWER than the 256-row tiles
-  return sizeof(T) == 2 && AMODE == A_PLAIN &&
-         (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_PLAIN || EPI == EPI_GELU_BWD);
-#else
-  return false;
-#endif
-}
-
 template <typename T, int AMODE, int EPI>
 static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
-  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 5;  // 5: v5 for the epilogues of gemm_v5_pick where its addressing applies, else v3; 3: v3 only
+  static const int ver = getenv("BSG_GEMM") ? atoi(getenv("BSG_GEMM")) : 5;  // 5: v5 for the epilogues of gemm_v5_pick where its addressing applies, else v3; 3: v3 only (the one A/B switch left)
+  const int tn3 = (g.N + 255) / 256, grid3 = std::min(((g.M + 255) / 256) * tn3, 256);
+  if constexpr (sizeof(T) == 4) {
+    if (g.x3) {  // pre-split (hi | lo) weights: ONLY the X3 instance of v3 reads that format, whatever BSG_GEMM says
+      hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI, 256, true>), dim3(grid3), dim3(512), 131072, st, g);
+      return;
+    }
+  }
   if (ver == 1) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<T, AMODE, EPI>), dim3(tiles), dim3(256), 65536, st, g);
-  } else if ((ver == 2 || g.N <= 192) && !(sizeof(T) == 4 && g.x3)) {
+  } else if (ver == 2 || g.N <= 192) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
   } else if (ver >= 5 && gemm_v5_pick<EPI>() && gemm_v5_ok<AMODE>(g, sizeof(T))) {
@@ -1335,32 +1109,8 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
       const int tiles = (g.M / 256) * (g.N / 256);
       hipLaunchKernelGGL((gemm_nt_kernel_v5<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);
     }
-#ifdef BSG_GEMM_V4
-  } else if (ver == 4 && gemm_v4_ok<AMODE>(g, sizeof(T))) {
-    if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN) {
-      const int tiles = (g.M / 256) * (g.N / 256);
-      hipLaunchKernelGGL((gemm_nt_kernel_v4<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);
-    }
-#endif
   } else {
-    const int tn = (g.N + 255) / 256;
-    const int tiles = ((g.M + 255) / 256) * tn;
-    static const int persist = getenv("BSG_GEMM_PERSIST") ? atoi(getenv("BSG_GEMM_PERSIST")) : 256;  // workgroups in the persistent grid = CUs (0 = one workgroup per tile); 512: slower
-    if constexpr (gemm_tm224_built<T, AMODE, EPI>()) {
-      if (gemm_pick_224(g)) {
-        const long tiles224 = (long)((g.M + 223) / 224) * tn;
-        const int grid = persist > 0 ? (int)std::min<long>(tiles224, persist) : (int)tiles224;
-        hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI, 224>), dim3(grid), dim3(512), 131072, st, g);
-        return;
-      }
-    }
-    const int grid = persist > 0 ? std::min(tiles, persist) : tiles;
-    if constexpr (sizeof(T) == 4) {
-      if (g.x3) {
-        hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI, 256, true>), dim3(grid), dim3(512), 131072, st, g);
-        return;
-      }
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(grid), dim3(512), 131072, st, g);
+    // persistent: one workgroup per CU walks the tiles (one workgroup per tile / 512 workgroups: measured slower)
+    hipLaunchKernelGGL((gemm_nt_kernel_v3<T, AMODE, EPI>), dim3(grid3), dim3(512), 131072, st, g);
   }
 }

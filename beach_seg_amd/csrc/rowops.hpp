@@ -129,13 +129,18 @@ __global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = ((const f32x4*)x)[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    const float z = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);  // 0 for finite values, NaN otherwise
+    if (!(z == 0.f)) m = INFINITY;  // a NaN would be dropped by fmaxf: report every non-finite input as +inf
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));  // non-negative floats order like uints
 }
-// state (int32, in the same workspace region, persistent across steps while the caller keeps the workspace): [0] overflow
-// flag of the LAST backward, [1] back-off exponent, [2] clean backwards since the last change, [3] overflows so far.
+// state (int32, in the same workspace region, persistent across steps while the caller keeps the workspace -- the C ABI never
+// allocates device memory of its own, so the guard's memory is the caller's like everything else; one guard per workspace):
+// [0] overflow flag of the LAST backward, [1] back-off exponent, [2] clean backwards since the last change, [3] dgrad overflows
+// so far, [4] the LAST backward's input (grad_pred, or the forward's pred_masks) was itself non-finite, [5] backwards dropped
+// for that reason so far, [6] raised by a train-mode forward whose pred_masks were non-finite, consumed by the next backward.
 __global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __restrict__ scale, int target_exp,
                                   int* __restrict__ state) {
   const float m = __builtin_bit_cast(float, absmax[0]);
@@ -146,10 +151,28 @@ __global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __
   scale[0] = exp2f((float)k);
   scale[1] = exp2f((float)-k);
   state[0] = 0;
+  // non-finite INPUT -- grad_pred itself, or the forward that saved this backward's activations (state[6], raised by the
+  // forward's own check of pred_masks: the reference smooth-L1 turns a NaN prediction into a FINITE gradient) -- is a bad
+  // batch or a forward overflow, not the dgrad chain's doing
+  state[4] = !(m < INFINITY) || state[6] != 0;
+  state[6] = 0;
+}
+// forward, train mode, f16 / x3: any non-finite element of pred_masks raises state[6] for the backward that follows
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long n4, int* __restrict__ flag) {
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    const float z = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
+    bad |= !(z == 0.f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 // Overflow guard of the half-precision dgrad chain (what torch's GradScaler does on the host): any non-finite element of
 // the final prompt gradient raises state[0]; the caller skips its optimiser step (engine: the flag rides the gradient
 // all-reduce), and the next backward runs with 4x more headroom.  After 1000 clean backwards one bit is given back.
+// The back-off is raised ONLY when the incoming grad_pred was finite, i.e. when the half-precision chain really overflowed:
+// a non-finite input (state[4]) drops the step as well but leaves the scale alone -- a few bad batches must not push the
+// scale target down and flush small gradient elements for thousands of steps.
 __global__ void grad_finite_kernel(const float* __restrict__ g, long n4, int* __restrict__ state) {
   bool bad = false;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -160,7 +183,8 @@ __global__ void grad_finite_kernel(const float* __restrict__ g, long n4, int* __
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(state, 1);
 }
 __global__ void grad_state_kernel(int* __restrict__ state) {
-  if (state[0]) { state[1] = min(state[1] + 2, 14); state[2] = 0; state[3] += 1; }
+  if (state[0] && state[4]) { state[5] += 1; }
+  else if (state[0]) { state[1] = min(state[1] + 2, 14); state[2] = 0; state[3] += 1; }
   else if (++state[2] >= 1000 && state[1] > 0) { state[1] -= 1; state[2] = 0; }
 }
 

@@ -125,8 +125,8 @@ static Plan make_plan(const bsg_model* m, int B, int train) {
     p.add("relhT", -1, (size_t)B * nh * hp * npad * 4);
     p.add("relwT", -1, (size_t)B * nh * 32 * npad * 4);
     if (m->c.embed_split) p.add("dx_split", -1, (size_t)B * (N / 2) * 3 * D * es);
-    p.add("gscale", -1, 256);  // f16: f32 [0] S, [1] 1/S, [8] max |grad_pred| (bits); i32 [16] overflow flag of the last
-                               // backward, [17] back-off exponent, [18] clean backwards, [19] overflows so far
+    p.add("gscale", -1, 256);  // f16 / x3: f32 [0] S, [1] 1/S, [8] max |grad_pred| (bits); i32 [16..22] the overflow guard's state
+                               // (rowops.hpp grad_scale_kernel: flag, back-off exponent, clean backwards, overflows, ...)
   }
   return p;
 }
@@ -149,26 +149,12 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   static bool once = (allow_lds(gemm_nt_kernel<T, AM, EPI>, 65536), allow_lds(gemm_nt_kernel_v2<T, AM, EPI>, 3 * 49152),
                       allow_lds(gemm_nt_kernel_v3<T, AM, EPI>, 131072), true);
   (void)once;
-  if constexpr (gemm_tm224_built<T, AM, EPI>()) {
-    static bool once224 = (allow_lds(gemm_nt_kernel_v3<T, AM, EPI, 224>, 131072), true);
-    (void)once224;
-  }
   if constexpr (sizeof(T) == 2 && AM == A_PLAIN && gemm_v5_pick<EPI>()) {
     static bool once5 = (allow_lds(gemm_nt_kernel_v5<T, EPI>, 131072), true);
     (void)once5;
   }
-#ifdef BSG_GEMM_V4
-  if constexpr (sizeof(T) == 2 && AM == A_PLAIN) {
-    static bool once4 = (allow_lds(gemm_nt_kernel_v4<T, EPI>, 131072), true);
-    (void)once4;
-  }
-#endif
   const bool plain_rows = AM == A_PLAIN && g.a_rpg <= 0;
   if (g.a_rpg <= 0) { g.a_rpg = AM == A_FEAT ? g.tokens : (g.M > 0 ? g.M : 1); g.a_gstride = 0; }
-  static const int stagger = getenv("BSG_GEMM_STAGGER") ? atoi(getenv("BSG_GEMM_STAGGER")) : 0;  // tried: no gain (CUs are not in lock-step), kept for experiments
-  g.stagger = stagger;
-  static const int group_m = getenv("BSG_GEMM_GROUP_M") ? atoi(getenv("BSG_GEMM_GROUP_M")) : 0;
-  g.group_m = group_m;
   if constexpr (sizeof(T) == 4) {
     if (m->c.gemm_x3) { g.x3 = 1; g.acc_scale = 1.0f / 32.0f; }  // Linear weights are stored x 2^5 in this mode (header)
   }
@@ -176,14 +162,12 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
   // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
-  static const bool split_tail = !getenv("BSG_GEMM_NO_TAIL_SPLIT");
   constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
-  bool tm224 = false;
-  if constexpr (gemm_tm224_built<T, AM, EPI>()) tm224 = plain_rows && gemm_pick_224(g);
+  bool no_tail = false;
   if constexpr (sizeof(T) == 4) {
-    if (g.x3) tm224 = true;  // x3: pre-split weights are readable by the 256 x 256 kernel only -> no 128^2 tail launch
+    if (g.x3) no_tail = true;  // x3: pre-split weights are readable by the 256 x 256 kernel only -> no 128^2 tail launch
   }
-  if (!tm224 && split_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
+  if (!no_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
     const long tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
     const long full = tiles / 256, rem = tiles % 256;
     const long tm_main = (full * 256) / tn;  // row tiles that fit in the full rounds
@@ -227,37 +211,42 @@ template <typename T, int MODE, int DC> static void launch_conv_halo(const ConvA
   hipLaunchKernelGGL((conv3x3_kernel<T, MODE, DC>), dim3(a.W / 32, (a.H - ty0 * CONV_TR) / G::TR, B), dim3(256), lds, st, b);
 }
 template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int dc, int B, int ty0, hipStream_t st) {
-  static const bool ring_env = !getenv("BSG_CONV_NO_RING");
   if (dc == 128) {  // BASELINE config 5: the 288 KB filter bank does not fit the ring kernel's LDS -> halo-tile kernel, two K passes
     launch_conv_halo<T, MODE, 128>(a, B, ty0, st);
     return;
   }
   if constexpr (sizeof(T) == 2) {
-    if (ring_env) {
-      static bool once = (allow_lds(conv3x3_ring_kernel<T, MODE>, CR_LDS), allow_lds(conv3x3_ring8_kernel<T, MODE>, CR_LDS), true);
-      (void)once;
-      // BSG_CONV_RING8: 0 = the four-wave walker for both modes, 1 = the anti-phase eight-wave walker for the fused forward
-      // only, 2 (default) = for the dgrad as well (A/B runs)
-      static const int ring8 = getenv("BSG_CONV_RING8") ? atoi(getenv("BSG_CONV_RING8")) : 2;
-      ConvRingArgs r{};
-      r.c = a; r.y_begin = ty0 * CONV_TR; r.batch = B;
-      const int strips = a.W / 32, steps_total = (a.H - r.y_begin) / CR_ROWS;
-      r.nsplit = conv_row_split(B * strips, steps_total);
-      const int items = B * strips * r.nsplit;
-      if (ring8 >= (MODE == CONV_FWD_FUSED ? 1 : 2))
-        hipLaunchKernelGGL((conv3x3_ring8_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(512), CR_LDS, st, r);
-      else
-        hipLaunchKernelGGL((conv3x3_ring_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(256), CR_LDS, st, r);
-      return;
-    }
+    static bool once = (allow_lds(conv3x3_ring8_kernel<T, MODE>, CR_LDS), true);
+    (void)once;
+    ConvRingArgs r{};
+    r.c = a; r.y_begin = ty0 * CONV_TR; r.batch = B;
+    const int strips = a.W / 32, steps_total = (a.H - r.y_begin) / CR_ROWS;
+    r.nsplit = conv_row_split(B * strips, steps_total);
+    const int items = B * strips * r.nsplit;
+    hipLaunchKernelGGL((conv3x3_ring8_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(512), CR_LDS, st, r);
+    return;
   }
   launch_conv_halo<T, MODE, 64>(a, B, ty0, st);
 }
 
 // dK/dV launch: 16-bit dtypes stream 128-query tiles when the padded statistics rows hold the rounded-up length
-// (BSG_DKV_QT=64 forces the 64-query form: A/B runs)
-template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t st, bool x3 = false) {
+// the one-wave-per-SIMD form (attention_kv4.hpp, its own translation unit attention_kv4.hip): 16-bit dtypes
+bool bsg_dkv4_ok(const AttnBwdKvArgs& k);
+void bsg_launch_dkv4(const AttnBwdKvArgs& k, int dtype_bf16, hipStream_t st);
+template <typename T> static void launch_dkv4(const AttnBwdKvArgs& k, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) bsg_launch_dkv4(k, std::is_same<T, bf16_t>::value, st);
+}
+// variant: 0 = default (16-bit dtypes: the one-wave-per-SIMD kernel where the token grid allows it, else eight waves),
+// 1 = eight waves (one workgroup per CU), 2 = two four-wave workgroups per CU (measured 3 % SLOWER than eight waves: twice
+// the LDS-DMA per key row and a barrier per 64 queries; kept for A/B runs through bsg_op_attention only)
+template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t st, bool x3 = false, int variant = 0) {
   constexpr bool tr = sizeof(T) == 2;
+  if constexpr (tr) {
+    if (variant == 0 && bsg_dkv4_ok(k)) {
+      launch_dkv4<T>(k, st);
+      return;
+    }
+  }
   const dim3 kgrid(((k.hp + 7) / 8) * k.nh * k.S);
   if constexpr (!tr) {
     if (x3) {  // exact-f32 storage, three f16 MFMAs per f32 MFMA quadruple (attention.hpp mma32_x3)
@@ -269,8 +258,14 @@ template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t
     }
   }
   if constexpr (tr) {
-    static const int qt_env = getenv("BSG_DKV_QT") ? atoi(getenv("BSG_DKV_QT")) : 128;
-    if (qt_env == 128 && ((k.N + 127) & ~127) <= k.hp * 32) {
+    if (variant == 2 && k.hp % 4 == 0 && ((k.N + 63) & ~63) <= k.hp * 32) {  // two four-wave workgroups per CU (attention.hpp, NW = 4)
+      constexpr int lds = 2 * DkvK<T, true, 64>::STAGE;
+      static bool once4 = (allow_lds(attn_bwd_dkv_kernel<T, true, 64, false, 4>, lds), true);
+      (void)once4;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, 64, false, 4>), dim3((k.hp / 4) * k.nh * k.S), dim3(256), lds, st, k);
+      return;
+    }
+    if (((k.N + 127) & ~127) <= k.hp * 32) {
       constexpr int lds = 2 * DkvK<T, true, 128>::STAGE;
       static bool once = (allow_lds(attn_bwd_dkv_kernel<T, true, 128>, lds), true);
       (void)once;
@@ -457,6 +452,14 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     launch_conv<T, CONV_FWD_FUSED>(a, dc, B, 0, st);
     CHECK_LAUNCH();
   }
+  if (train && (std::is_same<T, f16_t>::value || (std::is_same<T, float>::value && m->c.gemm_x3))) {
+    // overflow guard of the scaled dgrad chain (rowops.hpp): a forward that already produced non-finite predictions must not
+    // count as an overflow of the backward that follows
+    const long n4 = (long)B * 3 * m->c.canvas_h * m->c.canvas_w / 4;
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, pred, n4,
+                       (int*)(c.template at<float>("gscale") + 16) + 6);
+    CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -585,7 +588,10 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       static bool once = (allow_lds(attn_bwd_dq_kernel<T, tr>, 160 * 1024), true);
       (void)once;
       {
-        ProfScope ps(m, st, PC_ATTN_BWD_DQ, 6.0 * B * nh * (double)N * N * 64);
+        // ALGORITHMIC work of the attention backward (SURVEY.md section 8 d): 2 x the forward's matmuls = 8 N^2 d per head, credited
+        // half to each of the two kernels that share it.  (They EXECUTE 6 + 8 = 14 N^2 d: both recompute S and dP; a one-pass
+        // flash backward executes 10.  Rounds 1-3 credited the executed count, which flattered both kernels by 1.75x.)
+        ProfScope ps(m, st, PC_ATTN_BWD_DQ, 4.0 * B * nh * (double)N * N * 64);
         const dim3 qgrid(((N + 127) / 128) * nh * B);
         const int relh_lds = 4 * 32 * (hp | 1) * 4;
         bool x3_done = false;
@@ -605,7 +611,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
       {
-        ProfScope ps(m, st, PC_ATTN_BWD_DKV, 8.0 * B * nh * (double)N * N * 64);
+        ProfScope ps(m, st, PC_ATTN_BWD_DKV, 4.0 * B * nh * (double)N * N * 64);
         launch_dkv<T>(k, st, m->c.gemm_x3 != 0);
       }
       CHECK_LAUNCH();
@@ -948,7 +954,7 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
                              const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
                              size_t scratch_bytes) {
   if (!qkv || !rel_cat || !out || !lse2 || !scratch) return fail("bsg_op_attention: null argument");
-  if ((which & 6) && (!rel_catT || !dout || !dqkv)) return fail("bsg_op_attention: backward needs rel_catT, dout, dqkv");
+  if ((which & 62) && (!rel_catT || !dout || !dqkv)) return fail("bsg_op_attention: backward needs rel_catT, dout, dqkv");
   if (hp % 2 || hp > 64 || wp > 32 || wp % 4) return fail("bsg_op_attention: bad token grid %d x %d", hp, wp);
   if (scratch_bytes < bsg_op_attention_scratch_bytes(S, nh, hp)) return fail("bsg_op_attention: scratch too small");
   hipStream_t st = (hipStream_t)stream;
@@ -996,6 +1002,30 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
     k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
     launch_dkv<T>(k, st);
+    CHECK_LAUNCH();
+  }
+  if (which & 16) {  // A/B: the eight-wave dK / dV kernel (one workgroup per CU)
+    AttnBwdKvArgs k{};
+    k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
+    k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
+    k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    launch_dkv<T>(k, st, false, 1);
+    CHECK_LAUNCH();
+  }
+  if (which & 32) {  // A/B: two four-wave workgroups per CU
+    AttnBwdKvArgs k{};
+    k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
+    k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
+    k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    launch_dkv<T>(k, st, false, 2);
+    CHECK_LAUNCH();
+  }
+  if (which & 8) {  // A/B: the one-wave-per-SIMD dK / dV kernel on the same tables
+    AttnBwdKvArgs k{};
+    k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
+    k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
+    k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    launch_dkv4<T>(k, st);
     CHECK_LAUNCH();
   }
   return 0;

@@ -97,6 +97,7 @@ class PromptTrainEngine:
         self._touched_f = self._flat[P * n: P * n + P]
         self._overflow_f = self._flat[P * n + P:]
         self.skipped_steps = torch.zeros((), dtype=torch.int64, device=dev)  # steps dropped by the overflow guard
+        self._last_batch = 0
 
     def step(self, pixel_values: torch.Tensor, label_color: torch.Tensor, yesdata: torch.Tensor,
              prompt_idx: torch.Tensor, prompt_mask_color: torch.Tensor) -> torch.Tensor:
@@ -116,7 +117,7 @@ class PromptTrainEngine:
 
     def _step(self, pixel_values, prompt_idx, prompt_mask_color, loss_and_grad) -> torch.Tensor:
         m = self.model
-        B = pixel_values.shape[0]
+        B = self._last_batch = pixel_values.shape[0]
         self._flat.zero_()
         prompts = ops.prompt_gather(self.params, prompt_idx)  # stack + Normalize
         pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True)
@@ -136,3 +137,14 @@ class PromptTrainEngine:
                        self.rows, self.steps.clamp_min(1), self.lr, self.betas, self.eps, self.weight_decay,
                        grad_scale=1.0 / self.world, touched=touched)
         return loss.detach()
+
+    def overflow_metrics(self) -> dict:
+        """State of the f16 / x3 overflow guard for logging (ONE host synchronisation; call it per epoch, not per step):
+        steps dropped on any rank, this rank's back-off exponent (the dgrad chain runs 2^-backoff below its target scale),
+        true dgrad overflows, and backwards dropped because the incoming gradient itself was non-finite (bad batch)."""
+        m = self.model
+        out = {"skipped_steps": int(self.skipped_steps), "backoff_exp": 0, "dgrad_overflows": 0, "nonfinite_input_steps": 0}
+        if (m.dtype == torch.float16 or getattr(m, "gemm_x3", False)) and self._last_batch and m._last_ws is not None:
+            st = m.grad_overflow_state(self._last_batch, m._last_ws).tolist()
+            out.update(backoff_exp=st[1], dgrad_overflows=st[3], nonfinite_input_steps=st[5])
+        return out

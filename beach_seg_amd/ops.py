@@ -351,7 +351,8 @@ def attention_scratch(S: int, nh: int, hp: int, device) -> torch.Tensor:
 def attention(which: int, qkv: torch.Tensor, rel_cat: torch.Tensor, S: int, nh: int, hp: int, wp: int, out: torch.Tensor,
               lse2: torch.Tensor, scratch: torch.Tensor, rel_catT: torch.Tensor | None = None,
               dout: torch.Tensor | None = None, dqkv: torch.Tensor | None = None) -> None:
-    """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV.  bf16 or f16 tensors:
+    """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV (bits 3-5: its A/B
+    variants, see the header).  bf16 or f16 tensors:
     qkv (S*N, 3*nh*64), rel_cat ([LH+LW], 64) / rel_catT, dout / out (S*N, nh*64), dqkv like qkv; lse2 f32 (S, nh, hp*32)."""
     _need_gpu(qkv, rel_cat, out, lse2, scratch)
     lib = N.load()

@@ -29,6 +29,7 @@ class Accumulator:
         self.world, self.process_group = world, process_group
         self.current_date = None
         self.current_pred_counter = None
+        self._reduced = False  # world > 1: the current counter already holds the SUM over ranks
         self.on_finish = on_finish
         self.finished: list[tuple[str, torch.Tensor]] = []
 
@@ -63,6 +64,10 @@ class Accumulator:
             if self.current_pred_counter is not None:
                 self.save_current()
             self.initialize_current(date)
+        if self.world > 1 and self._reduced:
+            # the counter holds the ranks' SUM: local votes on top of it would diverge between ranks and never be re-synchronised
+            raise RuntimeError(f"Accumulator.update for date {date!r} after its votes were reduced across ranks "
+                               "(result() / save_current() / reduce_votes()); finalise a date only after its last update")
         if disjoint:
             ops.vote_paste(self.current_pred_counter, masks, crops.to(self.device), crop_size)
             return

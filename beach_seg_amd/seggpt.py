@@ -335,13 +335,14 @@ class SegGptNative(torch.nn.Module):
         return g
 
     def grad_overflow_state(self, batch: int, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """int32 device view [overflow flag of the last backward, back-off exponent, clean backwards, overflows so far] of
-        the f16 overflow guard (`include/beach_seg_amd.h`, region "gscale"); all zero for the other dtypes.  `ws`: the
-        workspace of that backward (default: the engine's last one).  No synchronisation: act on it on the stream."""
+        """int32 device view [overflow flag of the last backward, back-off exponent, clean backwards, dgrad overflows so far,
+        last input was non-finite, backwards dropped for a non-finite input, pending forward flag] of the f16 / x3 overflow guard
+        (`include/beach_seg_amd.h`, region "gscale"); all zero for the other dtypes.  `ws`: the workspace of that backward
+        (default: the engine's last one).  No synchronisation: act on it on the stream."""
         ws = ws if ws is not None else (self._last_ws if self._last_ws is not None else self.workspace(batch, True))
         off, nb = C.c_size_t(), C.c_size_t()
         N.check(self._lib.bsg_workspace_region(self._h, batch, 1, b"gscale", -1, C.byref(off), C.byref(nb)))
-        return ws[off.value + 64: off.value + 80].view(torch.int32)
+        return ws[off.value + 64: off.value + 92].view(torch.int32)
 
     def last_backward_overflowed(self) -> bool:
         """f16 only: did the last autograd backward produce a non-finite prompt gradient?  (Host synchronisation, like

@@ -29,6 +29,11 @@ import sys
 import time
 from pathlib import Path
 
+# HSA / RCCL variables have to be in the environment BEFORE anything initialises the HIP runtime (`import torch` alone does
+# not, `torch.cuda.set_device` does): this pool's host driver only supports dmabuf IPC, and without the setting RCCL's
+# multi-process set-up fails with `hipIpcGetMemHandle: invalid argument`.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
@@ -52,6 +57,24 @@ def flops_per_tile(g) -> tuple[float, float]:
     fwd = 2 * patch + (L + m + 1) * (lin + att_mm + rel) + dec + conv + head  # two streams up to the merge block
     bwd = L * (lin + 2 * att_mm + rel) + dec + conv + head + patch / 2        # image stream only; prompt half of the embed dgrad
     return fwd, bwd
+
+
+def attention_roofline(prof: dict, nprof: int, peak: float) -> dict:
+    """`roofline`-style block for the attention kernels from the library's per-launch HIP events.  `achieved` is priced on
+    SURVEY.md section 8(d)'s ALGORITHMIC count: forward 4 N^2 d per head (QK^T + PV), backward 8 N^2 d (2 x the forward's
+    matmuls), whatever the kernels execute (the two-kernel backward recomputes S and dP in both: 14 N^2 d; a one-pass flash
+    backward executes 10 N^2 d, quoted beside it as `flash_convention`)."""
+    f = prof.get("attn_fwd", (0.0, 0.0, 0))
+    bwd_ms = sum(prof[k][0] for k in prof if k.startswith("attn_bwd"))
+    bwd_fl = sum(prof[k][1] for k in prof if k.startswith("attn_bwd"))
+    tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0.0
+    return {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+            "fwd": {"ms_per_step": round(f[0] / nprof, 3), "achieved": tf(f[1], f[0]), "frac": round(tf(f[1], f[0]) / peak, 4),
+                    "algorithmic": "4 N^2 d per (stream, head)"},
+            "bwd": {"ms_per_step": round(bwd_ms / nprof, 3), "achieved": tf(bwd_fl, bwd_ms), "frac": round(tf(bwd_fl, bwd_ms) / peak, 4),
+                    "algorithmic": "8 N^2 d per (stream, head) (SURVEY 8d)",
+                    "flash_convention": {"flops": "10 N^2 d", "achieved": tf(bwd_fl * 1.25, bwd_ms), "frac": round(tf(bwd_fl * 1.25, bwd_ms) / peak, 4)}},
+            "ms_per_step": round((f[0] + bwd_ms) / nprof, 3)}
 
 
 def cpu_model_name() -> str:
@@ -167,7 +190,11 @@ def main() -> None:
     ap.add_argument("--no-config5", action="store_true", help="skip the config5 extra (BASELINE configs[4] geometry, ~20 s)")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra profiled steps after the timed region")
     ap.add_argument("--loss-variant", default="reference", choices=["reference", "per_sample"])
+    ap.add_argument("--lib", default="", help="A/B runs only: another build of libbsg_hip.so (tools/build_at.sh) instead of the in-tree one")
     args = ap.parse_args()
+    if args.lib:
+        from beach_seg_amd import _native
+        _native.use_library(args.lib)
 
     import torch
     import torch.distributed as dist
@@ -183,11 +210,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     # BSG_BENCH_REHEARSE=1: rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of
     # RCCL, which refuses two ranks on one device); the reported number is meaningless then.
-    rehearse = bool(os.environ.get("BSG_BENCH_REHEARSE"))
-    dev = torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
+    # BSG_BENCH_REHEARSE=cpu: the same control flow with NO device at all (tests/test_host_logic.py runs it under
+    # torch.distributed.run with two ranks): launch contract, rendezvous, the step's collective on a buffer of the real layout,
+    # barrier + max-over-ranks timing and the JSON line -- no kernel runs, nothing is measured, the line says so.
+    rehearse = os.environ.get("BSG_BENCH_REHEARSE", "")
+    cpu_rehearsal = rehearse == "cpu"
+    dev = torch.device("cpu") if cpu_rehearsal else torch.device("cuda:0" if rehearse else f"cuda:{local_rank}")
+    if not cpu_rehearsal:
+        torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -203,26 +234,38 @@ def main() -> None:
     # BSG_BENCH_CPU_WEIGHTS: build the (bit-identical) synthetic weights on the host -- under rocprofv3 --pmc the
     # thousands of tiny generator kernels would otherwise dominate the profiling run
     wdev = torch.device("cpu") if os.environ.get("BSG_BENCH_CPU_WEIGHTS") else dev
-    model = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dtype, gemm_x3=args.dtype == "f32x3")
-    log("model ready")
     B, P = args.batch, args.prompts
     Hh, W = g.image_size[0] // 2, g.image_size[1]
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)  # per-rank DATA
-    rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
-    pix, label_color, prompt_mask_color = rn(B, 3, Hh, W), rn(B, 3, Hh, W), rn(B, 3, Hh, W)
-    yes = torch.ones(B, 1, Hh, W, dtype=torch.bool, device=dev)
-    pgen = torch.Generator(device=dev).manual_seed(1007)  # the trainable prompts start IDENTICAL on every rank
-    engine = PromptTrainEngine(model, torch.rand(P, 3, Hh, W, device=dev, generator=pgen), lr=1e-3,
-                               loss_variant=args.loss_variant)  # (and the engine broadcasts rank 0's copy)
-    idx = (torch.arange(B, device=dev) + rank * B) % P
+    if cpu_rehearsal:
+        args.no_extras = args.no_cpu_baseline = True
+        from beach_seg_amd.engine import reduce_prompt_grads
 
-    def step():
-        return engine.step(pix, label_color, yes, idx, prompt_mask_color)
+        flat = torch.zeros(P * 3 * Hh * W + P + 1)  # the engine's reduce buffer: [P x n gradients | P touched flags | overflow flag]
+
+        def step():
+            flat.fill_(float(rank + 1))
+            reduce_prompt_grads(flat)  # the step's ONE data-path collective (gloo here, RCCL on the GPUs)
+            return flat[0] / (world * (world + 1) / 2)  # 1.0 when every rank contributed
+    else:
+        model = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dtype, gemm_x3=args.dtype == "f32x3")
+        log("model ready")
+        gen = torch.Generator(device=dev).manual_seed(7 + rank)  # per-rank DATA
+        rn = lambda *s: torch.randn(*s, device=dev, generator=gen)
+        pix, label_color, prompt_mask_color = rn(B, 3, Hh, W), rn(B, 3, Hh, W), rn(B, 3, Hh, W)
+        yes = torch.ones(B, 1, Hh, W, dtype=torch.bool, device=dev)
+        pgen = torch.Generator(device=dev).manual_seed(1007)  # the trainable prompts start IDENTICAL on every rank
+        engine = PromptTrainEngine(model, torch.rand(P, 3, Hh, W, device=dev, generator=pgen), lr=1e-3,
+                                   loss_variant=args.loss_variant)  # (and the engine broadcasts rank 0's copy)
+        idx = (torch.arange(B, device=dev) + rank * B) % P
+
+        def step():
+            return engine.step(pix, label_color, yes, idx, prompt_mask_color)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_rehearsal:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -271,6 +314,11 @@ def main() -> None:
             "whole_step_tflops_per_gpu": round(tiles / world / dt * train_flops / 1e12, 1),
             "whole_step_frac_of_mfma_peak": round(tiles / world / dt * train_flops / 1e12 / peak, 4),
         }
+        if rehearse:
+            out["rehearsal"] = ("cpu: control flow only, no kernel ran -- value is NOT a measurement" if cpu_rehearsal
+                                else "every rank on cuda:0 over gloo -- value is NOT a measurement")
+            if cpu_rehearsal and abs(float(loss) - 1.0) > 1e-6:
+                raise SystemExit(f"rehearsal collective returned {float(loss)}, expected 1.0")
         if prof is not None:
             ms, fl, n = prof["gemm"]
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -284,6 +332,7 @@ def main() -> None:
                             f"({tprof * 1e3:.1f} ms/step with the events on)"}
             out["kernel_time_ms_per_step"] = {k: round(v[0] / nprof, 3) for k, v in prof.items()}
             out["kernel_tflops"] = {k: round(v[1] / (v[0] * 1e-3) / 1e12, 1) if v[0] > 0 else 0.0 for k, v in prof.items()}
+            out["attention_roofline"] = attention_roofline(prof, nprof, peak)
         if world == 1 and not args.no_extras:
             # ---- second half of BASELINE.json's metric: inference forward, batch B, one hipGraph (configs[3] inner loop)
             graphed = model.capture_forward(B)
@@ -316,7 +365,7 @@ def main() -> None:
             #      MFMA (same rate as bf16, loss-scaled dgrad) and exact-f32 MFMA (bit-exact masks)
             del engine, model
             torch.cuda.empty_cache()
-            for key, dt_, Bx, nw, nt in (("f16", torch.float16, B, 2, 5), ("f32x3", torch.float32, 16, 1, 3),
+            for key, dt_, Bx, nw, nt in (("f16", torch.float16, B, 2, 5), ("f32x3", torch.float32, B, 1, 3),
                                          ("f32_parity", torch.float32, 16, 1, 2)):
                 # f32x3: float32 storage / attention / LayerNorm, the Linear GEMMs as three f16 MFMAs on 22-bit operand splits
                 mx = SegGptNative(synth_state_dict(g, seed=0, device=wdev), g, device=dev, dtype=dt_, gemm_x3=(key == "f32x3"))
@@ -331,13 +380,16 @@ def main() -> None:
                 torch.cuda.synchronize()
                 tx = (time.perf_counter() - t1) / nt
                 out[f"{key}_mode_tiles_per_s"] = round(Bx / tx, 2)
+                # x3 issues three f16 MFMAs per product: its honest ceiling is the f16 MFMA peak / 3 ("f32-class" TFLOP/s)
+                pk = {"f16": PEAK_BF16_TFLOPS, "f32x3": round(PEAK_BF16_TFLOPS / 3, 1), "f32_parity": 157.3}[key]
+                tfl = Bx / tx * TRAIN_FLOPS_PER_TILE / 1e12
                 out[f"{key}_mode"] = {"batch": Bx, "ms_per_step": round(tx * 1e3, 1), "steps": nt, "warmup": nw,
-                                      "tflops": round(Bx / tx * TRAIN_FLOPS_PER_TILE / 1e12, 1),
-                                      "peak_tflops": PEAK_BF16_TFLOPS if key == "f16" else 157.3, "loss_finite": bool(torch.isfinite(lx))}
+                                      "tflops": round(tfl, 1), "peak_tflops": pk, "frac": round(tfl / pk, 4),
+                                      "loss_finite": bool(torch.isfinite(lx))}
                 if key == "f32x3":
-                    out[f"{key}_mode"]["note"] = ("float32 storage / softmax / LayerNorm; every GEMM and attention MFMA as three f16 MFMAs on "
-                                                  "22-bit operand splits (conv on exact-f32 MFMA): same parity as f32_parity; no single peak "
-                                                  "applies, peak_tflops is the exact-f32 MFMA peak it replaces")
+                    out[f"{key}_mode"]["note"] = ("the fastest mode INSIDE north_star's 1e-3 on every reference vector (tests/test_gpu_parity.py): "
+                                                  "float32 storage / softmax / LayerNorm, every GEMM and attention MFMA as three f16 MFMAs on "
+                                                  "22-bit operand splits (3x3 conv on exact-f32 MFMA); peak_tflops = dense f16 MFMA peak / 3")
                 log(f"{key} mode: {tx * 1e3:.0f} ms/step at B={Bx} = {Bx / tx:.1f} tiles/s")
                 del ex, mx
                 torch.cuda.empty_cache()

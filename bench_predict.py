@@ -14,6 +14,7 @@ device (`ops.tile_frontend`), pushed through the ViT-L forward in batches, decod
 leaving the GPU."""
 import argparse, json, os, sys, time
 from pathlib import Path
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HIP runtime initialises (dmabuf IPC only on this pool: RCCL needs it)
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, str(Path(__file__).resolve().parent))

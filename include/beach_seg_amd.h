@@ -107,9 +107,13 @@ int bsg_backward(bsg_model* m, void* stream, int batch, const float* grad_pred, 
 /* BSG_DTYPE_F16 overflow guard: the backward checks the prompt gradient it produced; workspace region "gscale"
  * (bsg_workspace_region(m, batch, 1, "gscale", -1, ...)) holds, as int32 at byte offset 64: [0] 1 if the LAST backward on
  * this workspace produced a non-finite gradient (the caller must then skip its optimiser step, as torch's GradScaler
- * does), [1] the back-off exponent in force (raised by 2 per overflow: 4x more headroom for the next backward; lowered by
- * 1 after 1000 clean backwards), [2] clean backwards since the last change, [3] overflows so far.  Device memory: read it
- * on the stream (no host round trip is needed to act on it).  Always 0 for the other dtypes. */
+ * does), [1] the back-off exponent in force (raised by 2 per overflow OF THE DGRAD CHAIN, i.e. only when grad_pred itself
+ * was finite: 4x more headroom for the next backward; lowered by 1 after 1000 clean backwards), [2] clean backwards since
+ * the last change, [3] dgrad overflows so far, [4] 1 if the LAST backward's input was itself non-finite -- grad_pred, or the
+ * pred_masks of the train-mode forward on this workspace ([6], raised by bsg_forward, consumed by the backward) -- i.e. a bad
+ * batch or a forward overflow: the step is dropped, the scale is left alone, [5] backwards dropped for that reason so far.  Device
+ * memory: read it on the stream (no host round trip is needed to act on it).  Always 0 for the other dtypes.  The state
+ * lives in the caller's workspace because this library owns no device memory: one guard per workspace. */
 
 /* Same, for a grad_pred the caller guarantees to be zero on canvas rows < first_row (what bsg_loss_fwd_bwd produces
  * with first_row = H/2: the reference loss only covers the query half, src/model.py:53-57).  The decoder dgrad then
@@ -236,7 +240,9 @@ int bsg_op_gemm_epilogue(void* stream, int dtype, int epilogue, int M, int N, in
 /* The fused attention kernels on their own (unit tests and micro-benchmarks), T = bf16 or f16 (dtype 1 / 2): qkv T[S*N][3*nh*64] (q | k | v column
  * blocks, head h at columns h*64), N = hp*wp tokens per stream; rel_cat / rel_catT as in the weight table (slots 18 / 19);
  * `which` bit 0: forward -> out T[S*N][nh*64], lse2 f32[S][nh][hp*32]; bit 1: dQ (needs out, lse2 of a forward and dout
- * T[S*N][nh*64]) -> dqkv q columns; bit 2: dK, dV (needs the tables a dQ launch left in `scratch`) -> dqkv k, v columns.
+ * T[S*N][nh*64]) -> dqkv q columns; bit 2: dK, dV (needs the tables a dQ launch left in `scratch`) -> dqkv k, v columns, by the
+ * kernel the backward uses (one wave per SIMD where the token grid allows it).  A/B bits, same inputs and outputs as bit 2:
+ * bit 3 the one-wave-per-SIMD kernel, bit 4 the eight-wave kernel, bit 5 two four-wave workgroups per CU.
  * scratch: >= bsg_op_attention_scratch_bytes bytes. */
 size_t bsg_op_attention_scratch_bytes(int S, int nh, int hp);
 int bsg_op_attention(void* stream, int dtype, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,

@@ -144,3 +144,38 @@ def test_vit_large_predict_composition_vs_oracle_pipeline():
     print(f"[measured] predict composition ViT-L f32: pred rel err {err:.2e}, {nbad} of {want.size} final classes differ")
     assert err < 1e-4
     assert np.array_equal(got, want)  # f32 mode: bit-exact final classes
+
+
+def test_config5_full_depth_batch_invariance_and_prompt_gradient():
+    """BASELINE configs[4] at its OWN size (`SegGptGeometry.config5()`: canvas 1024 x 512, hidden 2048, 32 heads, mlp 8192,
+    decoder 128, all 24 layers; bf16, B = 8, one GPU): the train-step call sequence of the engine.  Samples 0 and 7 must give
+    bit-identical predictions and prompt gradients alone (B = 1) and in the batch, the gradient must be finite and non-zero,
+    and the dgrad must be linear (power-of-two scaling commutes with every rounding of the chain).  Parity against the oracle
+    is pinned at two layers (`test_wide_grid_and_wide_encoder_vs_oracle`); the full depth is too slow for the CPU."""
+    from beach_seg_amd.seggpt import SegGptNative
+    from test_gpu_parity import _models
+
+    _models.clear()  # free the resident ViT-L of the tests above (one model at a time)
+    torch.cuda.empty_cache()
+    g = SegGptGeometry.config5()
+    assert g.num_hidden_layers == 24 and g.hidden_size == 2048 and g.decoder_hidden_size == 128 and g.mlp_dim == 8192
+    model = SegGptNative(synth_state_dict(g, seed=0, device=DEV), g, device=DEV, dtype=torch.bfloat16)
+    B, Hh, W = 8, g.image_size[0] // 2, g.image_size[1]
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    pix, prm, pmask = rn(B, 3, Hh, W), rn(B, 3, Hh, W), rn(B, 3, Hh, W)
+    gpred = torch.zeros(B, 3, 2 * Hh, W, device=DEV)
+    gpred[:, :, Hh:, :] = rn(B, 3, Hh, W) * 1e-5
+    pred = model._run_forward(pix, prm, pmask, 0, train=True)
+    assert torch.isfinite(pred).all() and float(pred.std()) > 0
+    g_b = model._run_backward(gpred, B, first_row=Hh)
+    assert torch.isfinite(g_b).all() and float(g_b.abs().max()) > 0
+    g_2 = model._run_backward(2 * gpred, B, first_row=Hh)
+    assert torch.equal(g_2, 2 * g_b)
+    for i in (0, 7):
+        p1 = model._run_forward(pix[i:i + 1], prm[i:i + 1], pmask[i:i + 1], 0, train=True)
+        assert torch.equal(p1[0], pred[i]), f"sample {i}: prediction depends on the batch"
+        g1 = model._run_backward(gpred[i:i + 1], 1, first_row=Hh)
+        assert torch.equal(g1[0], g_b[i]), f"sample {i}: max diff {float((g1[0] - g_b[i]).abs().max()):.3e}"
+    del model
+    torch.cuda.empty_cache()

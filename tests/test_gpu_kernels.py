@@ -139,3 +139,16 @@ def test_attention_kernels_vs_torch(hp, wp, S, nh, gain, dtype):
     # P / dS / output rounding of the operand type (2^-9 bf16, 2^-12 f16) against an fp32 reference on the same operands
     assert max(errs) < (1.5e-2 if dtype == torch.bfloat16 else 2.5e-3)
     assert torch.isfinite(dqkv.float()).all() and torch.isfinite(lse2).all()
+    # the dK / dV kernel variants (one wave per SIMD with 3 / 2 key rows per wave = the default on these grids, eight waves,
+    # two four-wave workgroups) run the same arithmetic in the same order on the tables the dQ launch left: bit-identical
+    scratch = ops.attention_scratch(S, nh, hp, DEV)
+    ops.attention(3, qkv, rc, S, nh, hp, wp, out, lse2, scratch, rc.t().contiguous(), dout, dqkv)
+    want = dqkv[:, D:].clone()
+    for bit in (8, 16, 32):
+        dqkv[:, D:].zero_()
+        ops.attention(bit, qkv, rc, S, nh, hp, wp, out, lse2, scratch, rc.t().contiguous(), dout, dqkv)
+        if bit == 8:
+            ref = dqkv[:, D:].clone()
+            assert rel(ref[:, :D], gk) < 1.5e-2 and rel(ref[:, D:], gv) < 1.5e-2
+        assert torch.equal(dqkv[:, D:], ref), f"dK / dV variant bit {bit} differs from the one-wave-per-SIMD kernel"
+    del want

@@ -154,16 +154,30 @@ def test_f16_overflow_guard_skips_the_step_and_backs_off():
     assert st.tolist()[:2] == [0, 0] and int(eng.skipped_steps) == 0
     before = (eng.params.clone(), eng.exp_avg.clone(), eng.steps.clone())
     bad = pix.clone()
-    bad[0, 0, 3, 3] = float("inf")  # non-finite activations saved by the forward -> non-finite dgrad
+    bad[0, 0, 3, 3] = float("inf")  # non-finite activations -> non-finite pred -> the INCOMING grad_pred is already non-finite
     eng.step(bad, lab, yes, idx, pmc)
     torch.cuda.synchronize()
     st = net.grad_overflow_state(2)
-    assert st[0].item() == 1 and st[1].item() == 2 and st[3].item() == 1 and int(eng.skipped_steps) == 1
+    # the step is dropped, but a bad batch is not the dgrad chain's doing: the back-off stays where it was
+    assert st[0].item() == 1 and st[1].item() == 0 and st[3].item() == 0 and st[4].item() == 1 and st[5].item() == 1
+    assert int(eng.skipped_steps) == 1
     assert torch.equal(eng.params, before[0]) and torch.equal(eng.exp_avg, before[1]) and torch.equal(eng.steps, before[2])
-    eng.step(pix, lab, yes, idx, pmc)  # clean again: flag clears, the back-off stays, the step is applied
+    eng.step(pix, lab, yes, idx, pmc)  # clean again: flag clears, the step is applied
     st = net.grad_overflow_state(2)
-    assert st[0].item() == 0 and st[1].item() == 2 and int(eng.skipped_steps) == 1
+    assert st[0].item() == 0 and st[1].item() == 0 and st[4].item() == 0 and int(eng.skipped_steps) == 1
     assert not torch.equal(eng.params, before[0]) and torch.isfinite(eng.params).all()
+    # a TRUE overflow of the half-precision chain on a finite gradient: push the scale target 2^12 up by hand (max |S * grad_pred|
+    # lands at 2^20 > 65504) -> flag, step dropped, 4x more headroom for the next backward, counted as a dgrad overflow
+    before = (eng.params.clone(), eng.exp_avg.clone(), eng.steps.clone())
+    net.grad_overflow_state(2)[1] = -12
+    eng.step(pix, lab, yes, idx, pmc)
+    torch.cuda.synchronize()
+    st = net.grad_overflow_state(2)
+    assert st[0].item() == 1 and st[1].item() == -10 and st[3].item() == 1 and st[4].item() == 0 and st[5].item() == 1
+    assert int(eng.skipped_steps) == 2 and torch.equal(eng.params, before[0]) and torch.equal(eng.steps, before[2])
+    m = eng.overflow_metrics()
+    assert m == {"skipped_steps": 2, "backoff_exp": -10, "dgrad_overflows": 1, "nonfinite_input_steps": 1}
+    net.grad_overflow_state(2)[1] = 0
     # autograd boundary
     p = P0[:2].to(DEV).requires_grad_(True)
     out = net(pixel_values=bad, prompt_pixel_values=p, prompt_masks=pmc)

@@ -243,3 +243,51 @@ def test_data_parallel_gradient_reduction_gloo_world2():
     want[4 * n:5 * n] = 2 * 5
     want[P * n + 0], want[P * n + 3], want[P * n + 4] = 1, 2, 1
     assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+
+
+def test_bench_two_rank_launch_contract_cpu_rehearsal():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank, 127.0.0.1), in the
+    device-less rehearsal mode: rendezvous, the step's collective on a buffer of the engine's layout, barrier + max-over-ranks
+    timing, and ONE JSON line from rank 0 carrying the N = 2 contract fields.  No kernel runs (N > 1 throughput stays
+    unmeasured until the driver's multi-GPU node runs it)."""
+    import json
+    import os
+    import subprocess
+    import sys as _sys
+    from pathlib import Path
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, BSG_BENCH_REHEARSE="cpu", MASTER_ADDR="127.0.0.1")
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--geometry", "tiny",
+           "--prompts", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["metric"] == "train tiles/sec" and out["unit"] == "tiles/s" and out["higher_is_better"] is True
+    assert "rehearsal" in out and "NOT a measurement" in out["rehearsal"]
+
+
+def test_sharded_accumulator_refuses_votes_after_the_rank_sum():
+    """Sharded predict (`Accumulator(world > 1)`): once a date's counters hold the SUM over ranks, a further `update` for that
+    date would add local votes on top of it on one rank only -- the mirror raises instead of diverging; a new date starts clean."""
+    from beach_seg_amd.predict import Accumulator
+
+    acc = Accumulator((4, 4), ("nodata", "sand", "water", "veg"), torch.device("cpu"), world=2)
+    assert acc._reduced is False  # set in __init__: no AttributeError on the reduce paths before the first date
+    with pytest.raises(AssertionError):
+        acc.save_current()
+    acc.initialize_current("d0")
+    acc.reduce_votes()  # (no process group here: the reduction itself is a no-op, the state change is what is under test)
+    with pytest.raises(RuntimeError, match="after its votes were reduced"):
+        acc.update("d0", torch.zeros(0, 4, dtype=torch.int32), torch.zeros(0, 2, 2, dtype=torch.uint8), 2)
+    acc.initialize_current("d1")
+    assert acc._reduced is False

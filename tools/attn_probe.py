@@ -1,12 +1,14 @@
 """Attention micro-benchmark + check against a plain torch fp32 reference of the same op (GPU box):
     python tools/attn_probe.py [S=64] [check]
-Times attn_fwd / attn_bwd_dq / attn_bwd_dkv of the library BSG_LIB points at (default: the in-tree build) on the
+Times attn_fwd / attn_bwd_dq / attn_bwd_dkv of the library BSG_AB_LIB points at (tools/_ab.py; default: the in-tree build) on the
 ViT-L geometry (16 heads, 56 x 28 tokens), random N(0,1)-scaled q/k/v as LayerNorm+QKV would produce them."""
 import sys, time
 from pathlib import Path
 import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+from tools._ab import pick_lib
+pick_lib()
 from beach_seg_amd import ops
 from beach_seg_amd.seggpt import _rel_cat
 
@@ -30,7 +32,7 @@ call = lambda w: ops.attention(w, qkv, rc, S, nh, hp, wp, out, lse2, scratch, rc
 call(7)
 torch.cuda.synchronize()
 res = {}
-for name, w, fl in (("fwd", 1, 4.0), ("dq", 2, 6.0), ("dkv", 4, 8.0)):
+for name, w, fl in (("fwd", 1, 4.0), ("dq", 2, 4.0), ("dkv", 4, 4.0), ("dkv_1wave", 8, 4.0), ("dkv_8wave", 16, 4.0), ("dkv_2x4wave", 32, 4.0)):  # algorithmic: fwd 4 N^2 d, bwd 8 N^2 d over its two kernels
     for _ in range(2):
         call(w)
     torch.cuda.synchronize()
@@ -45,6 +47,19 @@ for name, w, fl in (("fwd", 1, 4.0), ("dq", 2, 6.0), ("dkv", 4, 8.0)):
     res[name] = ms
     print(f"{name}: {ms:.3f} ms  {fl * S * nh * N * N * 64 / ms / 1e9:.0f} TFLOP/s algorithmic", flush=True)
 print("RESULT", " ".join(f"{k}={v:.3f}" for k, v in res.items()), flush=True)
+
+# the one-wave-per-SIMD dK / dV kernel against the eight-wave one on the same tables: same arithmetic, same order
+call(2 | 16)
+ref_kv = dqkv[:, D:].clone()
+dqkv[:, D:].zero_()
+call(8)
+torch.cuda.synchronize()
+print("one-wave-per-SIMD dkv vs eight-wave dkv: max abs diff", float((dqkv[:, D:].float() - ref_kv.float()).abs().max()), "bit-identical", torch.equal(dqkv[:, D:], ref_kv), flush=True)
+
+dqkv[:, D:].zero_()
+call(4)
+torch.cuda.synchronize()
+print("default dkv vs eight-wave dkv: bit-identical", torch.equal(dqkv[:, D:], ref_kv), flush=True)
 
 if check:
     s_chk = min(S, 2)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_at.sh <git-rev> <out.so>: compile the library as of <git-rev> (for same-box A/B runs via BSG_LIB=...)
+# tools/build_at.sh <git-rev> <out.so>: compile the library as of <git-rev> (for same-box A/B runs: bench.py --lib <out.so>, BSG_AB_LIB=<out.so> for the probes in tools/)
 set -e
 rev=$1; out=$2; d=$(mktemp -d)
 git archive "$rev" beach_seg_amd/csrc include | tar -x -C "$d"
