@@ -240,6 +240,22 @@ DEVI void gelu_both_pk(const f32x2& x, f32x2& y, f32x2& dy) {
   y = x * cdf;
   dy = fma2(f32x2{0.39894228040143267794f, 0.39894228040143267794f} * x, e, cdf);
 }
+// gelu alone on an element pair: the arithmetic of gelu_f on v_pk_* instructions (x * (0.5 (1 + erf)) where gelu_f has
+// (0.5 x) (1 + erf): the same bits, a power-of-two factor commutes with the rounding)
+DEVI f32x2 gelu_pk(const f32x2& x) {
+  const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])};
+  const f32x2 u = (x * f32x2{-0.72134752044448170368f, -0.72134752044448170368f}) * x;
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+  const f32x2 d = fma2(f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, ax, f32x2{1.f, 1.f});
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = fma2(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+  p = fma2(p, t, f32x2{1.421413741f, 1.421413741f});
+  p = fma2(p, t, f32x2{-0.284496736f, -0.284496736f});
+  p = fma2(p, t, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 er0 = fma2(-p * t, e, f32x2{1.f, 1.f});
+  const f32x2 er = f32x2{copysignf(er0[0], x[0]), copysignf(er0[1], x[1])};
+  return x * (f32x2{0.5f, 0.5f} * (f32x2{1.f, 1.f} + er));
+}
 DEVI float gelu_grad_f(float x) {
   const float ax = fabsf(x);
   const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);

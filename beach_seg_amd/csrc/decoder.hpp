@@ -156,8 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // 16-bit dtypes: persistent "column-strip walker" (conv3x3_ring8_kernel below).  One workgroup per CU (the whole 160 KB of LDS)
 // owns a work item = (image, 32-pixel column strip, row range) and walks it top to bottom in steps of 8 output rows:
-//   * the 72 KB filter bank [co][tap][ci] is staged in LDS ONCE per workgroup (rows padded to 1168 B: the 16 filter
-//     rows of a W fragment read land on distinct bank quads), not re-read from L2 by every wave for every tap;
+//   * the 72 KB filter bank [co][tap][ci] is staged in LDS ONCE per workgroup, not re-read from L2 by every wave for every
+//     tap.  Rows are padded to 1184 B = 74 sixteen-byte slots: a ds_read_b128 is served in four groups of 16 lanes that mix
+//     two fragment chunks ({0-3, 12-15, 20-27}: filter rows 0-3, 12-15 of chunk c with rows 4-11 of chunk c + 1), and with a
+//     pitch of 10 mod 16 slots the 16 (row, chunk) pairs of every group fall on 16 different slots of the 256-byte bank row
+//     (round 3's 1168 B = 9 mod 16 made 7 of them collide two-way: SQ_LDS_BANK_CONFLICT 0.36 per active LDS cycle);
 //   * the input rows live in an 18-row LDS ring (row slot = row mod 18, 36-pixel slots, chunk-swizzled by pixel); the 8
 //     rows of the NEXT step arrive by LDS-DMA (zero page for pixels outside the image) while the MFMAs of the current
 //     step run, so every input row is fetched once per strip (no vertical halo overlap) and the halo fill does not
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 //   * the wait for the DMA sits BEFORE the epilogue's stores (vmcnt counts stores too).
 // (Round 2's four-wave form of the walker -- one wave per SIMD, MFMA phase and epilogue one after the other -- was superseded
 // by the eight-wave anti-phase form in round 3 and removed in round 4: DESIGN.md section 8.)
-constexpr int CR_ROWS = 8, CR_RING = 18, CR_SLOT_PX = 36, CR_WROW = 1168;
+constexpr int CR_ROWS = 8, CR_RING = 18, CR_SLOT_PX = 36, CR_WROW = 1184;
 constexpr int CR_W_BYTES = 64 * CR_WROW, CR_RING_BYTES = CR_RING * CR_SLOT_PX * 128, CR_LDS = CR_W_BYTES + CR_RING_BYTES;
 __device__ __attribute__((aligned(256))) const unsigned char bsg_conv_zero_page[256] = {0};
 
@@ -353,6 +356,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ring8_kernel(ConvRingArgs ra) 
             q += __shfl_xor(q, 16, 64);
             q += __shfl_xor(q, 32, 64);
             const float rstd = rsqrtf(q * (1.f / 64.f) + a.eps);
+#ifdef BSG_CONV_PK  // measured (round 4): the LayerNorm affine + GELU + head on v_pk_* pairs: 3.02 vs 2.96 ms -- beside the other wave
+            // group's MFMAs packed f32 instructions are no faster than the scalar pair (guide: an anti-lever beside MFMAs), and
+            // the pair alignment costs a spilled register
+            const f32x2 rs2 = f32x2{rstd, rstd};
+            f32x2 p0 = f32x2{0.f, 0.f}, p1 = p0, p2 = p0;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+              for (int r = 0; r < 4; r += 2) {
+                const f32x2 xn = f32x2{v[ni][r], v[ni][r + 1]} * rs2;
+                const f32x2 tt = gelu_pk(fma2(xn, f32x2{cg[ni][r], cg[ni][r + 1]}, f32x2{cbe[ni][r], cbe[ni][r + 1]}));
+                p0 = fma2(tt, f32x2{cw0[ni][r], cw0[ni][r + 1]}, p0);
+                p1 = fma2(tt, f32x2{cw1[ni][r], cw1[ni][r + 1]}, p1);
+                p2 = fma2(tt, f32x2{cw2[ni][r], cw2[ni][r + 1]}, p2);
+              }
+            }
+            float o0 = p0[0] + p0[1], o1 = p1[0] + p1[1], o2 = p2[0] + p2[1];
+#else
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
@@ -362,6 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ring8_kernel(ConvRingArgs ra) 
                 o0 += tt * cw0[ni][r]; o1 += tt * cw1[ni][r]; o2 += tt * cw2[ni][r];
               }
             }
+#endif
             o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
             o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
             o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
