@@ -33,8 +33,22 @@ template <int DC> struct ConvGeo {
   static_assert(DC == 64 || DC == 128, "decoder width: 64 or 128 channels");
   static constexpr int RW = DC == 64 ? 4 : 2, TR = 4 * RW, HALO = (TR + 2) * 34, NO = DC / 16, HALVES = DC / 64;
 };
-template <typename T, int MODE, int DC>
+// X3 (T = float only, bsg_config.gemm_x3): "float32 at three f16 MFMAs" as in gemm_nt_kernel_v3<..., X3> -- two f32 k-steps
+// (2 x 16 channels) side by side form one 32-deep f16 operand, each fragment split hi = f16(x), lo = f16(x - hi); hi*hi + hi*lo +
+// lo*hi on v_mfma_f32_16x16x32_f16 (3 x 16 cycles) in place of eight v_mfma_f32_16x16x4_f32 (8 x 32).  Weights are split
+// in-kernel, x 2^5 so that the lo halves of sigma = 0.02 filters stay normal f16 numbers; the accumulator is scaled back exactly.
+DEVI void x3_split8(const f32x4& x0, const f32x4& x1, float s, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a0 = x0[e] * s, a1 = x1[e] * s;
+    const f16_t h0 = (f16_t)a0, h1 = (f16_t)a1;
+    hi[e] = h0; hi[4 + e] = h1;
+    lo[e] = (f16_t)(a0 - (float)h0); lo[4 + e] = (f16_t)(a1 - (float)h1);
+  }
+}
+template <typename T, int MODE, int DC, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  static_assert(!X3 || sizeof(T) == 4, "the three-term f16 split is the float32 kernel's option");
   typedef typename Traits<T>::Chunk Chunk;
   typedef ConvGeo<DC> G;
   constexpr int EPC = Traits<T>::EPC, CPP = 64 / EPC;  // chunks per pixel of one 64-channel pass: 8 (16-bit) / 16 (f32)
@@ -73,6 +87,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll 1  // rolled: with 128 accumulator registers a fully unrolled tap loop hoists operand loads into spills
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - 3 * dy;
+      if constexpr (X3) {
+#pragma unroll
+        for (int kp = 0; kp < KS / 2; ++kp) {
+          const int c0 = fchunk + 8 * kp, c1 = c0 + 4;
+#pragma unroll
+          for (int n0 = 0; n0 < NO; n0 += 4) {  // four output-channel tiles at a time: their split filters are 64 registers
+            f16x8 wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const char* wp = (const char*)a.w + (((long)((n0 + i) * 16 + frow) * 9 + tap) * DC + half * 64) * sizeof(T);
+              x3_split8(*(const f32x4*)(wp + c0 * 16), *(const f32x4*)(wp + c1 * 16), 32.0f, wh[i], wl[i]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < NM; ++mi) {
+              const int pix = (G::RW * wave + (mi >> 1) + dy) * 34 + (mi & 1) * 16 + frow + dx;
+              f16x8 ah, al;
+              x3_split8(*(const f32x4*)(halo + pix * PB + ((c0 ^ (pix & (CPP - 1))) << 4)),
+                        *(const f32x4*)(halo + pix * PB + ((c1 ^ (pix & (CPP - 1))) << 4)), 1.0f, ah, al);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                mma16(acc[n0 + i][mi], wh[i], ah);
+                mma16(acc[n0 + i][mi], wh[i], al);
+                mma16(acc[n0 + i][mi], wl[i], ah);
+              }
+              __builtin_amdgcn_sched_barrier(0);  // (as in attention.hpp mma32_x3: keeps hipcc from hoisting all the splits)
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int c = fchunk + 4 * ks;
@@ -93,6 +137,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
     }
   }
 
+  if constexpr (X3) {  // the filters were multiplied by 2^5
+#pragma unroll
+    for (int i = 0; i < NO; ++i)
+#pragma unroll
+      for (int j = 0; j < NM; ++j) acc[i][j] *= 0.03125f;
+  }
   // acc[ni][mi][r]: pixel (y0 + RW*wave + (mi>>1), x0 + (mi&1)*16 + frow), channel ni*16 + 4*fchunk + r
 #pragma unroll
   for (int mi = 0; mi < NM; ++mi) {

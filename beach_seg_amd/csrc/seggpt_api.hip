@@ -201,18 +201,27 @@ static int conv_row_split(int base_items, int steps_total) {
   }
   return best;
 }
-template <typename T, int MODE, int DC> static void launch_conv_halo(const ConvArgs& a, int B, int ty0, hipStream_t st) {
+template <typename T, int MODE, int DC> static void launch_conv_halo(const ConvArgs& a, int B, int ty0, hipStream_t st, bool x3 = false) {
   typedef ConvGeo<DC> G;
   constexpr int lds = G::HALO * 64 * sizeof(T);
-  static bool once = (allow_lds(conv3x3_kernel<T, MODE, DC>, lds), true);
-  (void)once;
   ConvArgs b = a;
   b.ty0 = ty0;
-  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, DC>), dim3(a.W / 32, (a.H - ty0 * CONV_TR) / G::TR, B), dim3(256), lds, st, b);
+  const dim3 grid(a.W / 32, (a.H - ty0 * CONV_TR) / G::TR, B);
+  if constexpr (sizeof(T) == 4) {
+    if (x3) {  // float32 storage, three f16 MFMAs per product (bsg_config.gemm_x3)
+      static bool once3 = (allow_lds(conv3x3_kernel<T, MODE, DC, true>, lds), true);
+      (void)once3;
+      hipLaunchKernelGGL((conv3x3_kernel<T, MODE, DC, true>), grid, dim3(256), lds, st, b);
+      return;
+    }
+  }
+  static bool once = (allow_lds(conv3x3_kernel<T, MODE, DC>, lds), true);
+  (void)once;
+  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, DC>), grid, dim3(256), lds, st, b);
 }
-template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int dc, int B, int ty0, hipStream_t st) {
+template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int dc, int B, int ty0, hipStream_t st, bool x3 = false) {
   if (dc == 128) {  // BASELINE config 5: the 288 KB filter bank does not fit the ring kernel's LDS -> halo-tile kernel, two K passes
-    launch_conv_halo<T, MODE, 128>(a, B, ty0, st);
+    launch_conv_halo<T, MODE, 128>(a, B, ty0, st, x3);
     return;
   }
   if constexpr (sizeof(T) == 2) {
@@ -226,7 +235,7 @@ template <typename T, int MODE> static void launch_conv(const ConvArgs& a, int d
     hipLaunchKernelGGL((conv3x3_ring8_kernel<T, MODE>), dim3(std::min(items, 256)), dim3(512), CR_LDS, st, r);
     return;
   }
-  launch_conv_halo<T, MODE, 64>(a, B, ty0, st);
+  launch_conv_halo<T, MODE, 64>(a, B, ty0, st, x3);
 }
 
 // dK/dV launch: 16-bit dtypes stream 128-query tiles when the padded statistics rows hold the rounded-up length
@@ -449,7 +458,7 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
     a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
     ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * dc * dc);
-    launch_conv<T, CONV_FWD_FUSED>(a, dc, B, 0, st);
+    launch_conv<T, CONV_FWD_FUSED>(a, dc, B, 0, st, m->c.gemm_x3 != 0);
     CHECK_LAUNCH();
   }
   if (train && (std::is_same<T, f16_t>::value || (std::is_same<T, float>::value && m->c.gemm_x3))) {
@@ -517,7 +526,7 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     a.in = dconv; a.w = m->gw(10); a.out = dfeat; a.H = H; a.W = W; a.eps = m->c.layer_norm_eps;
     {
       ProfScope ps(m, st, PC_CONV, 2.0 * B * (H - ty0 * CONV_TR) * W * 9 * dc * dc);
-      launch_conv<T, CONV_PLAIN>(a, dc, B, ty0, st);
+      launch_conv<T, CONV_PLAIN>(a, dc, B, ty0, st, m->c.gemm_x3 != 0);
     }
     CHECK_LAUNCH();
     if (ph0 > 0) {  // token rows < ph0 receive exactly zero

@@ -137,7 +137,7 @@ def csrc_sha() -> str:
     return h.hexdigest()[:16]
 
 
-PMC_SUMMARY = ROOT / "profiles" / "r3_pmc_summary.json"
+PMC_SUMMARY = ROOT / "profiles" / "r4_pmc_summary.json"
 
 
 def gemm_hbm_traffic_per_launch() -> tuple[float | None, str]:
