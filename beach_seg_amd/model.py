@@ -107,7 +107,14 @@ class PromptModel(torch.nn.Module):
         # Lightning precision strings (src/config.py:35): "32-true" -> exact-f32 kernels, "bf16-*" -> bf16, "16-*" -> IEEE half
         dtype = (torch.float32 if conf.precision.startswith("32") else
                  torch.float16 if conf.precision.startswith("16") else torch.bfloat16)
-        # "32-x3": float32 storage / attention / LayerNorm with the Linear GEMMs as three f16 MFMAs (22-bit operands)
+        if dtype != torch.float32 and model is None:
+            import warnings
+            # measured against the reference-generated vectors (tests/test_gpu_parity.py)
+            warnings.warn(f"precision={conf.precision!r}: the 16-bit operand formats are OUTSIDE the reference's 1e-3 tolerance where "
+                          "attention is peaked, as in a trained checkpoint (ViT-L peaked fixture: float16 9.4e-3 prediction / 3.2e-2 "
+                          "prompt gradient, bfloat16 7.2e-2 / 2.6e-1).  Only '32-true' (exact f32) and '32-x3' (float32 storage, three f16 "
+                          "MFMAs per product, 2.4x faster) are inside it on every fixture.", stacklevel=2)
+        # "32-x3": float32 storage / softmax / LayerNorm with every GEMM, attention and conv MFMA as three f16 MFMAs (22-bit operands)
         self.model = model if model is not None else ml_util.load_model(conf.checkpoint, device=device, dtype=dtype,
                                                                         gemm_x3="x3" in conf.precision)
         self.train_metrics = MulticlassF1(self.num_classes, self.nodata_idx, self.model.device)

@@ -388,8 +388,8 @@ def main() -> None:
                                       "loss_finite": bool(torch.isfinite(lx))}
                 if key == "f32x3":
                     out[f"{key}_mode"]["note"] = ("the fastest mode INSIDE north_star's 1e-3 on every reference vector (tests/test_gpu_parity.py): "
-                                                  "float32 storage / softmax / LayerNorm, every GEMM and attention MFMA as three f16 MFMAs on "
-                                                  "22-bit operand splits (3x3 conv on exact-f32 MFMA); peak_tflops = dense f16 MFMA peak / 3")
+                                                  "float32 storage / softmax / LayerNorm, every GEMM, attention and 3x3-conv MFMA as three f16 "
+                                                  "MFMAs on 22-bit operand splits; peak_tflops = dense f16 MFMA peak / 3")
                 log(f"{key} mode: {tx * 1e3:.0f} ms/step at B={Bx} = {Bx / tx:.1f} tiles/s")
                 del ex, mx
                 torch.cuda.empty_cache()
