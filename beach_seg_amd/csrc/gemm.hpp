@@ -21,6 +21,7 @@ enum EpiMode {
   EPI_PLAIN = 5,      // out[m][n] = T(acc)
   EPI_GELU_BWD = 6,   // out[m][n] = T(acc * aux[m][n]),  aux = gelu'(h) saved by EPI_BIAS_GELU
   EPI_UNPATCH = 7,    // patch-embed dgrad: scatter rows into the (B,3,H/2,W) fp32 prompt-pixel gradient
+  EPI_BIAS_GELU_FWD = 8,  // inference: out[m][n] = T(gelu(acc + bias[n])) only -- no derivative is formed (a third less epilogue arithmetic)
   EPI_NONE = 9,       // diagnostics: no stores (accumulators kept alive), to price the epilogue
 };
 
@@ -100,8 +101,11 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
     for (int ni = 0; ni < 4; ++ni) {
       const int n = min(nw + ni * 16 + 4 * fchunk, g.N - 4);
       f32x4 v = acc[ni][mi];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_FEAT) v += bv ? bv[ni] : *(const f32x4*)(g.bias + n);
-      if (EPI == EPI_BIAS_GELU) {
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_FEAT) v += bv ? bv[ni] : *(const f32x4*)(g.bias + n);
+      if (EPI == EPI_BIAS_GELU_FWD) {
+        const f32x2 y0 = gelu_pk(f32x2{v[0], v[1]}), y1 = gelu_pk(f32x2{v[2], v[3]});
+        v = f32x4{y0[0], y0[1], y1[0], y1[1]};
+      } else if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
@@ -151,7 +155,7 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
 template <typename T, int EPI, int NMI = 4>
 DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int frow, int fchunk, const f32x4 (*ax)[4] = nullptr,
                         const f32x4* bv = nullptr) {  // bv: the sub-tile's four bias vectors (column blocks ni), loaded by the caller
-  if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD ||
+  if constexpr (sizeof(T) == 2 && (EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_GELU_BWD ||
                                    EPI == EPI_FEAT)) {
     if (!(g.N & 15)) {
       gemm_epilogue_wide16<T, EPI, NMI>(g, acc, mw, nw, frow, fchunk, ax, bv);
@@ -169,7 +173,7 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
       f32x4 v = acc[ni][mi];
       if (EPI == EPI_NONE) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
       if constexpr (sizeof(T) == 4) { if (g.acc_scale != 0.f) v *= g.acc_scale; }
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT) {
         const f32x4 b = bv ? bv[ni] : *(const f32x4*)(g.bias + n);
         v += b;
       }
@@ -189,6 +193,9 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
           }
         }
         *(typename Traits<T>::Vec4*)((T*)g.out + orow * g.ldo + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+      } else if (EPI == EPI_BIAS_GELU_FWD) {
+        const f32x2 y0 = gelu_pk(f32x2{v[0], v[1]}), y1 = gelu_pk(f32x2{v[2], v[3]});
+        *(typename Traits<T>::Vec4*)((T*)g.out + (long)m * g.ldo + n) = pack4<T>(y0[0], y0[1], y1[0], y1[1]);
       } else if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
@@ -779,8 +786,11 @@ DEVI void gemm_epilogue_v5_wide(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, i
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       f32x4 v = acc[ni][mi];
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) v += bv[ni];
-      if (EPI == EPI_BIAS_GELU) {
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD) v += bv[ni];
+      if (EPI == EPI_BIAS_GELU_FWD) {
+        const f32x2 y0 = gelu_pk(f32x2{v[0], v[1]}), y1 = gelu_pk(f32x2{v[2], v[3]});
+        v = f32x4{y0[0], y0[1], y1[0], y1[1]};
+      } else if (EPI == EPI_BIAS_GELU) {
         f32x4 y, dy;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
@@ -939,7 +949,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     f32x4 fa[2][8], fw[2][8];  // [k-step][row block]
     // the wave tile's eight bias vectors arrive under the K loop (inside the epilogue every re-load behind a store would
     // wait for L2 with nothing else on the SIMD)
-    constexpr bool kBias = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT;
+    constexpr bool kBias = EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_BIAS_RESID || EPI == EPI_FEAT;
     f32x4 bias8[8];
     if constexpr (kBias) {
 #pragma unroll
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
     // instruction cache (same box, ms per step, rolled vs unrolled: QKV 14.0 vs 14.5, fc1 + GELU 25.2 vs 26.3, plain dgrads
     // 28.4 vs 29.8).  The aux-operand epilogues keep the unrolled form: their double-buffered prefetch needs static register
     // names (rolled two by two, the buffers went to scratch: 263 vs 29 ms), and the pixel-shuffle one measured 9.8 vs 9.1.
-    constexpr bool kRolled = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU;
+    constexpr bool kRolled = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD;
     if constexpr (kRolled) {
 #pragma nounroll
       for (int q = 0; q < 4; ++q) {

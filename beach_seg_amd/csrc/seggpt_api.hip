@@ -162,7 +162,7 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   // Tile quantisation: with 256 x 256 tiles on 256 CUs a launch of R.f rounds pays ceil(R.f).  When the last round is
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
   // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
-  constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
+  constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
   bool no_tail = false;
   if constexpr (sizeof(T) == 4) {
     if (g.x3) no_tail = true;  // x3: pre-split weights are readable by the 256 x 256 kernel only -> no 128^2 tail launch
@@ -411,7 +411,8 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
       GemmArgs g{};
       g.A = ln_out; g.W = m->lw(l, 10); g.M = rows; g.N = mlp; g.K = D; g.lda = D;
       g.bias = (const float*)m->lw(l, 12); g.out = h_act; g.out2 = h_pre; g.ldo = mlp;
-      gemm<T, A_PLAIN, EPI_BIAS_GELU>(m, g, st);
+      if (train) gemm<T, A_PLAIN, EPI_BIAS_GELU>(m, g, st);      // + the derivative, saved for the dgrad
+      else gemm<T, A_PLAIN, EPI_BIAS_GELU_FWD>(m, g, st);         // inference: gelu alone (same bits of h_act)
       CHECK_LAUNCH();
     }
     float* x_out;

@@ -179,3 +179,20 @@ def test_config5_full_depth_batch_invariance_and_prompt_gradient():
         assert torch.equal(g1[0], g_b[i]), f"sample {i}: max diff {float((g1[0] - g_b[i]).abs().max()):.3e}"
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("gname,B", [("tiny", 3), ("vit_large", 8)])
+def test_inference_forward_equals_train_forward_bit_for_bit(gname, B):
+    """The inference forward runs fc1 with the gelu-only epilogue (`EPI_BIAS_GELU_FWD`: no derivative formed), the train forward
+    with the one that also saves gelu' for the dgrad: the activations -- hence the predictions -- must be the same bits (tiny:
+    the eight-wave / 128^2 GEMM path, ViT-L at B = 8: `gemm_nt_kernel_v5`)."""
+    from test_gpu_parity import geometry_of, model_for
+
+    model = model_for(gname, 0, torch.bfloat16)
+    g = geometry_of(gname)
+    Hh, W = g.image_size[0] // 2, g.image_size[1]
+    gen = torch.Generator(device=DEV).manual_seed(23)
+    pix, prm, pm = (torch.randn(B, 3, Hh, W, device=DEV, generator=gen) for _ in range(3))
+    p_train = model._run_forward(pix, prm, pm, 0, train=True).clone()
+    p_infer = model._run_forward(pix, prm, pm, 0, train=False)
+    assert torch.isfinite(p_infer).all() and torch.equal(p_train, p_infer)
