@@ -339,6 +339,91 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The thin last round of a persistent 256 x 256 launch (launch_gemm_rows in seggpt_api.hip): the same 128 x 128 tile and wave
+// layout as gemm_nt_kernel, but FOUR LDS stages with three K tiles of LDS-DMA in flight behind counted waits.  A tail is 128
+// workgroups on 256 CUs -- one per CU, nothing else resident -- so the two-stage kernel above paid a full HBM round trip per
+// K tile (measured 17 / 61 us at K = 1024 / 4096 where the MFMAs need 4 / 16).  The DMA is the asm form: hipcc drains the
+// builtin one before the next LDS read.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_nt_tail_kernel(GemmArgs g) {
+  constexpr int EPC = Traits<T>::EPC;
+  constexpr int BK = 8 * EPC;  // elements per 128-byte K tile
+  constexpr int NS = 4, STAGE = 32768;  // [stage][A 128 rows x 128 B | W 128 rows x 128 B]
+  typedef typename Traits<T>::Chunk Chunk;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.N + 127) >> 7, tiles_m = (g.M + 127) >> 7;
+  const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm << 7, n0 = tn << 7;
+
+  const int prow = lane >> 3, pchunk = lane & 7;
+  const char* a_src[4];
+  const char* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + prow;
+    const int sc = pchunk ^ (r & 7);
+    int m = m0 + r;
+    if (m >= g.M) m = g.M - 1;
+    a_src[i] = (const char*)g.A + ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda * sizeof(T) + sc * 16;
+    int n = n0 + r;
+    if (n >= g.N) n = g.N - 1;
+    w_src[i] = (const char*)g.W + (long)n * g.K * sizeof(T) + sc * 16;
+  }
+  auto stage = [&](int kt) {
+    const long k0 = (long)kt * BK * sizeof(T);
+    char* la = smem + (kt & (NS - 1)) * STAGE + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16_asm(a_src[i] + k0, la + i * 1024);
+      glds16_asm(w_src[i] + k0, la + 16384 + i * 1024);
+    }
+  };
+
+  const int wr = wave >> 1, wc = wave & 1;
+  const int frow = lane & 15, fchunk = lane >> 4;
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;  // >= NS - 1 (the launcher checks)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) stage(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed when at most the 8 pieces of each younger tile are outstanding (vmcnt retires in order)
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else wait_vm0();
+    __syncthreads();  // ... for every wave's pieces; and every wave is done reading tile kt - 1, whose stage is refilled now
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);
+    const char* la = smem + (kt & (NS - 1)) * STAGE;
+    const char* lw = la + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Chunk fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + frow;
+        const int rw = wc * 64 + i * 16 + frow;
+        const int c = fchunk + 4 * ks;
+        fa[i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+        fw[i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
+    }
+  }
+  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // v2: 256 x 128 tile, 8 waves (4 x 2, same 64 x 64 wave tile), THREE LDS stages of 48 KB.  Two K tiles of LDS-DMA
 // stay in flight across the (raw) barrier behind a counted s_waitcnt vmcnt(6): one block per CU, two waves per
 // SIMD, never a vmcnt(0) inside the loop.

@@ -183,6 +183,14 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
       a.a_rpg = a.M; b.a_rpg = b.M;
       launch_gemm<T, AM, EPI>(a, st);
       const int tiles_b = ((b.M + 127) / 128) * ((b.N + 127) / 128);
+      if constexpr (AM == A_PLAIN) {
+        if (b.K / (8 * Traits<T>::EPC) >= 3) {  // the four-stage pipeline's prologue requests three K tiles
+          static bool once_t = (allow_lds(gemm_nt_tail_kernel<T, EPI>, 131072), true);
+          (void)once_t;
+          hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI>), dim3(tiles_b, 1), dim3(256), 131072, st, b);
+          return;
+        }
+      }
       hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EPI>), dim3(tiles_b, 1), dim3(256), 65536, st, b);
       return;
     }
