@@ -28,7 +28,7 @@ SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_op_gemm_epilogue", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_tile_frontend", "bsg_decode_hf",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_op_gemm_epilogue", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_forward_rows", "bsg_tile_frontend", "bsg_decode_hf",
     "bsg_op_attention", "bsg_op_attention_scratch_bytes", "bsg_tif_image", "bsg_train_aug", "bsg_train_aug_bwd",
     "bsg_confusion_update", "bsg_loss_fwd_bwd_ids", "bsg_mask_rgb_norm",
 )
@@ -74,6 +74,7 @@ def load():
     lib.bsg_workspace_bytes.restype = sz
     lib.bsg_workspace_region.argtypes = [vp, i, i, C.c_char_p, i, C.POINTER(sz), C.POINTER(sz)]
     lib.bsg_forward.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, sz, i]
+    lib.bsg_forward_rows.argtypes = [vp, vp, i, vp, vp, vp, i, i, vp, vp, sz, i]
     lib.bsg_backward.argtypes = [vp, vp, i, vp, vp, vp, sz]
     lib.bsg_backward_rows.argtypes = [vp, vp, i, vp, i, vp, vp, sz]
     lib.bsg_forward_ensemble.argtypes = [vp, vp, i, vp, vp, vp, i, vp, vp, sz]

@@ -138,6 +138,9 @@ struct AttnArgs {
   void* dv;
   int S, nh, N, hp, wp;
   float scale;
+  // backward, dQ kernel: the caller reads dq of the queries [dq_begin, dq_end) only (dq_end = 0: up to N).  Workgroups whose 128
+  // queries lie outside still publish their relwT / relhT / delta columns (dK/dV reads them) and store zero dq rows.
+  int dq_begin, dq_end;
 };
 
 // 1-D grid -> (x, head, stream) with all x-blocks of one (stream, head) on the SAME XCD: they re-read the same
@@ -676,6 +679,18 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 1 : 2) void attn_bwd_dq_kerne
     dl += __shfl_xor(dl, 32, 64);
     if (h == 0 && q0 + col < a.N) a.delta[sh * npad + q] = -dl;  // negated: the dK/dV kernel starts its dP accumulator from it
   }
+  if ((bx + 1) * 128 <= a.dq_begin || (a.dq_end > 0 && bx * 128 >= a.dq_end)) {
+    // workgroup-uniform: nobody reads dq of these queries (bsg_backward_rows: their dO rows are exactly zero in the block of the
+    // top tap, so dq is; block 0 feeds the prompt half of the canvas only) -- the tables are out, the rows are zeroed
+    if (q0 + col < a.N) {
+      T* orow = (T*)a.dq + ((long)s * a.N + q) * a.ld + head * 64;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(typename Traits<T>::Vec4*)(orow + 32 * d + 8 * i + 4 * h) = pack4<T>(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   f32x16 dqt[2], ndl;  // ndl: loop-invariant initial accumulator of dP^T (all entries -delta[q])
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dqt[0][i] = 0.f; dqt[1][i] = 0.f; ndl[i] = -dl; }
@@ -845,6 +860,9 @@ struct AttnBwdKvArgs {
   int S, nh, N, hp, wp;
   float scale;
   int kr_begin, kr_count;  // attention_kv4.hpp only: the key rows [kr_begin, kr_begin + kr_count) this launch covers
+  // attention_kv4.hpp only (the other kernels compute everything, a superset): queries < q_begin (a multiple of 64) contribute
+  // exact zeros and are not streamed; only the first key_rows key rows are wanted (0 = all Hp), the others are NOT written
+  int q_begin, key_rows;
 };
 
 // LDS-DMA of a ROWS x RB-byte tile by NW waves (1 KiB per wave-instruction), optional chunk swizzle.

@@ -13,13 +13,17 @@ template <typename T, int R> static void launch_rows(AttnBwdKvArgs k, int kr_beg
   const dim3 grid((kr_count / (4 * R)) * k.nh * k.S);
   hipLaunchKernelGGL((attn_bwd_dkv4_kernel<T, R>), grid, dim3(256), lds, st, k);
 }
+static bool kv4_rows_ok(int r) { return r % 4 == 0 && r >= 8 && (r % 12 != 4 || r >= 16); }
+// key rows covered: the first key_rows when the caller wants no more and they split into 12- and 8-row groups, else all Hp
+static int kv4_rows(const AttnBwdKvArgs& k) { return k.key_rows > 0 && k.key_rows < k.hp && kv4_rows_ok(k.key_rows) ? k.key_rows : k.hp; }
 template <typename T> static void launch_all(const AttnBwdKvArgs& k, hipStream_t st) {
   // Hp = 12 a + 8 b key rows: `a` groups of 12 rows at three rows per wave, then `b` (0, 1 or 2) groups of 8 rows at two per wave
-  const int b = (k.hp % 12) == 0 ? 0 : ((k.hp % 12) == 8 ? 1 : 2), main_rows = k.hp - 8 * b;
+  const int rows = kv4_rows(k);
+  const int b = (rows % 12) == 0 ? 0 : ((rows % 12) == 8 ? 1 : 2), main_rows = rows - 8 * b;
   if (main_rows) launch_rows<T, 3>(k, 0, main_rows, st);
   if (b) launch_rows<T, 2>(k, main_rows, 8 * b, st);
 }
-bool bsg_dkv4_ok(const AttnBwdKvArgs& k) { return k.hp % 4 == 0 && k.hp >= 8 && k.hp != 4 && (k.hp % 12 != 4 || k.hp >= 16); }
+bool bsg_dkv4_ok(const AttnBwdKvArgs& k) { return kv4_rows_ok(k.hp) && k.q_begin % 64 == 0 && k.q_begin >= 0 && k.q_begin < k.N; }
 void bsg_launch_dkv4(const AttnBwdKvArgs& k, int dtype_bf16, hipStream_t st) {
   if (dtype_bf16) launch_all<bf16_t>(k, st);
   else launch_all<f16_t>(k, st);

@@ -69,14 +69,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnBwdKvArgs a) 
   const int ngrp = a.kr_count / (4 * R);
   int bx, head, s;
   attn_block_ids(ngrp, a.nh, a.S, bx, head, s);
-  const int nt_real = (a.N + QT - 1) / QT;
+  const int nq = a.N - a.q_begin;  // queries streamed: [q_begin, N), q_begin a multiple of 64 (an even number of steps)
+  const int nt_real = (nq + QT - 1) / QT;
   const int nt = (R & 1) ? (nt_real + 1) & ~1 : nt_real;  // R odd: an even number of steps (the extra one adds exact zeros, see below)
   const int kr0 = a.kr_begin + bx * 4 * R;
   const int krw = kr0 + R * wave;                   // wave w owns key rows krw .. krw + R - 1
   const long sh = (long)s * a.nh + head;
   const int npad = a.hp * 32;
-  const char* qbase = (const char*)a.q + ((long)s * a.N * a.ld + head * 64) * sizeof(T);
-  const char* dobase = (const char*)a.dout + ((long)s * a.N * a.ldo + head * 64) * sizeof(T);
+  const char* qbase = (const char*)a.q + (((long)s * a.N + a.q_begin) * a.ld + head * 64) * sizeof(T);
+  const char* dobase = (const char*)a.dout + (((long)s * a.N + a.q_begin) * a.ldo + head * 64) * sizeof(T);
 
   // loop-invariant K / V fragments of this wave's rows
   Chunk kx[R][C::KS_D], vx[R][C::KS_D];
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnBwdKvArgs a) 
   const unsigned swzc = (unsigned)((pchunk ^ swz<128>(prow)) << 4);
   const unsigned off_q = (unsigned)(prow * a.ld * (long)sizeof(T)) + swzc, off_do = (unsigned)(prow * a.ldo * (long)sizeof(T)) + swzc;
   const unsigned off_rw = (unsigned)(prow * (long)npad * 4) + swzc;
-  const char* rw_base = (const char*)(a.relwT + sh * 32 * npad);
-  const char* st_src = (const char*)((prow == 0 ? a.delta + sh * npad : a.relhT + (sh * a.hp + min(kr0 + max(prow - 1, 0), a.hp - 1)) * npad) + 4 * pchunk);
+  const char* rw_base = (const char*)(a.relwT + sh * 32 * npad + a.q_begin);
+  const char* st_src = (const char*)((prow == 0 ? a.delta + sh * npad : a.relhT + (sh * a.hp + min(kr0 + max(prow - 1, 0), a.hp - 1)) * npad) + a.q_begin + 4 * pchunk);
   const long q_step = (long)QT * a.ld * sizeof(T), do_step = (long)QT * a.ldo * sizeof(T);
   const unsigned lds_w = lds_addr(smem) + wave * 1024;  // this wave's piece of stage 0's Q tile (wave-uniform)
   auto issue_piece = [&](int t, int buf, int i) {
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnBwdKvArgs a) 
     if (i < 2) {
       const char* gb = i == 0 ? qbase : dobase;
       const long gl = i == 0 ? a.ld : a.ldo;
-      if (t * QT + QT <= a.N) {
+      if (t * QT + QT <= nq) {
         glds16_asm_s(gb + t * (i == 0 ? q_step : do_step), i == 0 ? off_q : off_do, lb + i * K_::TILE);
       } else {  // ragged last step: rows past the last query re-read it (their relwT columns hold -inf: P = 0)
-        const int r = min(t * QT + prow, a.N - 1);
+        const int r = min(t * QT + prow, nq - 1);
         glds16_asm(gb + (long)r * gl * sizeof(T) + swzc, smem + buf * STAGE + i * K_::TILE + wave * 1024);
       }
     } else if (i == 2) {

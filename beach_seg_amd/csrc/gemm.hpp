@@ -47,7 +47,8 @@ struct GemmArgs {
   const void* aux;  // T* (GELU_BWD pre-activation) or float* (resid / table)
   long ldaux;
   // A_FEAT / EPI_PLAIN row windows: GEMM row m <-> image m / a_rpg, token t_off + m % a_rpg (A_FEAT), and output
-  // row (m / o_rpg) * o_gstride + o_off + m % o_rpg (EPI_PLAIN); o_rpg == 0 means the identity
+  // row (m / o_rpg) * o_gstride + o_off + m % o_rpg (EPI_PLAIN); o_rpg == 0 means the identity.  EPI_FEAT with o_rpg:
+  // GEMM row m is token t_off + m % o_rpg of image m / o_rpg (the forward's decoder_embed over a token-row window)
   int t_off;
   int o_rpg;
   long o_gstride, o_off;
@@ -134,7 +135,8 @@ DEVI void gemm_epilogue_wide16(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, in
       const bool ok = mok && col < g.N;
       long off;
       if (EPI == EPI_FEAT) {
-        const int b = m / g.tokens, t = m % g.tokens;
+        const int rpg = g.o_rpg ? g.o_rpg : g.tokens;  // o_rpg: row window, GEMM row m = token t_off + m % o_rpg of image m / o_rpg
+        const int b = m / rpg, t = (g.o_rpg ? g.t_off : 0) + m % rpg;
         const int ph = t / g.wp, pw = t % g.wp;
         const int lg = g.feat_lg, p1 = col >> (lg + 4), p2 = (col >> lg) & 15, c = col & ((1 << lg) - 1);
         off = ((((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) << lg) + c;
@@ -217,7 +219,8 @@ DEVI void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, i
         *(f32x4*)((float*)g.out + (long)m * g.ldo + n) = v + r;
       } else if (EPI == EPI_FEAT) {
         // n = (p1*16 + p2)*C + c  ->  pixel (ph*16 + p1, pw*16 + p2), channel c, C = decoder_hidden_size   (HF:559-572)
-        const int b = m / g.tokens, t = m % g.tokens;
+        const int rpg = g.o_rpg ? g.o_rpg : g.tokens;
+        const int b = m / rpg, t = (g.o_rpg ? g.t_off : 0) + m % rpg;
         const int ph = t / g.wp, pw = t % g.wp;
         const int lg = g.feat_lg, p1 = n >> (lg + 4), p2 = (n >> lg) & 15, c = n & ((1 << lg) - 1);
         const long o = ((((long)b * g.himg + ph * 16 + p1) * g.wimg + pw * 16 + p2) << lg) + c;
@@ -1177,8 +1180,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_v5(GemmArgs g) {
 // variant it scheduled accumulator reads between the last MFMA and the settling nops (tests/test_kernel_isa.py checks the
 // compiled code of every instance for that hazard).
 template <int EPI> constexpr bool gemm_v5_pick() { return EPI != EPI_EMBED && EPI != EPI_UNPATCH && EPI != EPI_NONE; }
-template <int AMODE> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
-  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M && g.o_rpg == 0 &&
+template <int AMODE, int EPI = EPI_PLAIN> static inline bool gemm_v5_ok(const GemmArgs& g, size_t es) {
+  return AMODE == A_PLAIN && es == 2 && g.M % 256 == 0 && g.N % 256 == 0 && g.K % 128 == 0 && g.a_rpg >= g.M && (g.o_rpg == 0 || EPI == EPI_FEAT) &&
          (long)g.ldo * 4 * 16 < (1L << 31) && (long)g.ldaux * 4 * 16 < (1L << 31) &&
          (long)g.lda * 2 * 64 < (1L << 31) && (long)g.K * 2 * 64 < (1L << 31);
 }
@@ -1199,7 +1202,7 @@ static inline void launch_gemm(const GemmArgs& g, hipStream_t st) {
   } else if (ver == 2 || g.N <= 192) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel_v2<T, AMODE, EPI>), dim3(tiles), dim3(512), 3 * 49152, st, g);
-  } else if (ver >= 5 && gemm_v5_pick<EPI>() && gemm_v5_ok<AMODE>(g, sizeof(T))) {
+  } else if (ver >= 5 && gemm_v5_pick<EPI>() && gemm_v5_ok<AMODE, EPI>(g, sizeof(T))) {
     if constexpr (sizeof(T) == 2 && AMODE == A_PLAIN && gemm_v5_pick<EPI>()) {
       const int tiles = (g.M / 256) * (g.N / 256);
       hipLaunchKernelGGL((gemm_nt_kernel_v5<T, EPI>), dim3(std::min(tiles, 256)), dim3(256), 131072, st, g);

@@ -39,11 +39,15 @@ struct LnRow {
 template <typename T>
 __global__ __launch_bounds__(256, 4) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y, long ldy,
-                                                         int rows, int D, float eps) {
+                                                         int rows, int D, float eps, int in_rpg = 0, long in_gstride = 0,
+                                                         long in_off = 0) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
+  // in_rpg > 0: output row r (compact) reads input row (r / in_rpg) * in_gstride + in_off + r % in_rpg -- the row window of
+  // every stream gathered into consecutive rows (the decoder's tap LayerNorms under bsg_forward_rows)
+  const long xrow = in_rpg ? (long)(row / in_rpg) * in_gstride + in_off + row % in_rpg : row;
   LnRow r;
-  r.load(x + (long)row * D, lane, D, eps);
+  r.load(x + xrow * D, lane, D, eps);
   T* yr = y + (long)row * ldy;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -158,10 +162,12 @@ __global__ void grad_scale_kernel(const unsigned* __restrict__ absmax, float* __
   state[6] = 0;
 }
 // forward, train mode, f16 / x3: any non-finite element of pred_masks raises state[6] for the backward that follows
-__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long n4, int* __restrict__ flag) {
+// (plane4 > 0: only the last `keep4` float4 of every plane of `plane4` float4 are looked at -- bsg_forward_rows leaves the canvas
+// rows above its window unwritten; n4 then counts the looked-at float4)
+__global__ void nonfinite_flag_kernel(const float* __restrict__ x, long n4, int* __restrict__ flag, long plane4 = 0, long keep4 = 0) {
   bool bad = false;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 v = ((const f32x4*)x)[i];
+    const f32x4 v = ((const f32x4*)x)[plane4 ? (i / keep4) * plane4 + (plane4 - keep4) + i % keep4 : i];
     const float z = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
     bad |= !(z == 0.f);
   }

@@ -308,9 +308,10 @@ template <typename T> struct Ctx {
   }
 };
 
-template <typename T> static void ln_fwd(const Ctx<T>& c, const float* x, const void* g, const void* b, T* y, long ldy, int rows) {
+template <typename T> static void ln_fwd(const Ctx<T>& c, const float* x, const void* g, const void* b, T* y, long ldy, int rows,
+                                         int in_rpg = 0, long in_gstride = 0, long in_off = 0) {
   hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((rows + 3) / 4), dim3(256), 0, c.st, x, (const float*)g, (const float*)b, y,
-                     ldy, rows, c.m->c.hidden_size, c.m->c.layer_norm_eps);
+                     ldy, rows, c.m->c.hidden_size, c.m->c.layer_norm_eps, in_rpg, in_gstride, in_off);
 }
 template <typename T>
 static void ln_bwd(const Ctx<T>& c, const T* dy, long lddy, const float* x, const void* g, const float* dx_in, float* dx_out,
@@ -320,7 +321,8 @@ static void ln_bwd(const Ctx<T>& c, const T* dy, long lddy, const float* x, cons
 }
 
 template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int B, const float* pix, const float* prm,
-                                              const float* pmask, int emb, float* pred, void* ws, int train, int fe = 0) {
+                                              const float* pmask, int emb, float* pred, void* ws, int train, int fe = 0,
+                                              int first_row = 0) {
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, train), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
   const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, dc = m->c.decoder_hidden;
@@ -332,6 +334,14 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   float* relh_s = c.template at<float>("relh_s");
   T* taps = c.template at<T>("taps");
   T* feat = c.template at<T>("feat");
+  // bsg_forward_rows: pred_masks is wanted on canvas rows >= first_row only (the reference loss and decode read the query half,
+  // src/model.py:53-57, :251-255).  The decoder then starts at the 16-row tile holding the first pixel row the BACKWARD reads the
+  // saved conv output at (backward_impl: hb0 = 16 ph0 - 8 with ph0 = (first_row - 1) / 16), and decoder_embed at the token row
+  // whose pixels the 3x3 conv reaches from there (one pixel row above).  The encoder is untouched: every token attends to all.
+  const int ph0b = first_row > 0 ? (first_row - 1) / 16 : 0;
+  const int ty0f = std::max(0, 16 * ph0b - 8) / CONV_TR;   // first 16-row conv tile of the forward
+  const int tr0 = ty0f > 0 ? ty0f - 1 : 0;                 // first token row of the decoder feature map
+  const int ntok_f = (hp - tr0) * wp;                      // tokens per image in the window
 
   {
     const long total = (long)2 * B * N * 96;
@@ -449,15 +459,17 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     int ti;
     if (m->is_tap(l, &ti)) {
       if (l < m->c.merge_index) return fail("tap %d before merge_index %d", l, m->c.merge_index);
-      ln_fwd<T>(c, x_cur, m->gw(4), m->gw(5), taps + (long)ti * D, (long)nt * D, B * N);
+      // rows of the window, gathered: taps is [B * ntok_f][nt * D] (the whole (B N) x (nt D) array when first_row = 0)
+      ln_fwd<T>(c, x_cur, m->gw(4), m->gw(5), taps + (long)ti * D, (long)nt * D, B * ntok_f, tr0 ? ntok_f : 0, N, (long)tr0 * wp);
       CHECK_LAUNCH();
     }
   }
   {
     GemmArgs g{};
-    g.A = taps; g.W = m->gw(6); g.M = B * N; g.N = 256 * dc; g.K = nt * D; g.lda = (long)nt * D;
+    g.A = taps; g.W = m->gw(6); g.M = B * ntok_f; g.N = 256 * dc; g.K = nt * D; g.lda = (long)nt * D;
     g.bias = (const float*)m->gw(8); g.out = feat; g.tokens = N; g.wp = wp; g.himg = m->c.canvas_h; g.wimg = m->c.canvas_w;
     g.feat_lg = dc == 128 ? 7 : 6;
+    if (tr0) { g.o_rpg = ntok_f; g.t_off = tr0 * wp; }
     gemm<T, A_PLAIN, EPI_FEAT>(m, g, st);
     CHECK_LAUNCH();
   }
@@ -466,16 +478,17 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
     a.in = feat; a.w = m->gw(9); a.bias = (const float*)m->gw(11); a.out = train ? c.template at<T>("conv_out") : nullptr;
     a.ln_g = (const float*)m->gw(12); a.ln_b = (const float*)m->gw(13); a.head_w = (const float*)m->gw(14);
     a.head_b = (const float*)m->gw(15); a.pred = pred; a.H = m->c.canvas_h; a.W = m->c.canvas_w; a.eps = m->c.layer_norm_eps;
-    ProfScope ps(m, st, PC_CONV, 2.0 * B * a.H * a.W * 9 * dc * dc);
-    launch_conv<T, CONV_FWD_FUSED>(a, dc, B, 0, st, m->c.gemm_x3 != 0);
+    ProfScope ps(m, st, PC_CONV, 2.0 * B * (a.H - ty0f * CONV_TR) * a.W * 9 * dc * dc);
+    launch_conv<T, CONV_FWD_FUSED>(a, dc, B, ty0f, st, m->c.gemm_x3 != 0);
     CHECK_LAUNCH();
   }
   if (train && (std::is_same<T, f16_t>::value || (std::is_same<T, float>::value && m->c.gemm_x3))) {
     // overflow guard of the scaled dgrad chain (rowops.hpp): a forward that already produced non-finite predictions must not
     // count as an overflow of the backward that follows
-    const long n4 = (long)B * 3 * m->c.canvas_h * m->c.canvas_w / 4;
+    const long plane4 = (long)m->c.canvas_h * m->c.canvas_w / 4, keep4 = (long)(m->c.canvas_h - ty0f * CONV_TR) * m->c.canvas_w / 4;
+    const long n4 = (long)B * 3 * keep4;
     hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 2048)), dim3(256), 0, st, pred, n4,
-                       (int*)(c.template at<float>("gscale") + 16) + 6);
+                       (int*)(c.template at<float>("gscale") + 16) + 6, ty0f ? plane4 : 0L, keep4);
     CHECK_LAUNCH();
   }
   return 0;
@@ -551,8 +564,14 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
     CHECK_LAUNCH();
   }
   bool dx_valid = false;
+  // Row windows of the attention backward (exact: only zeros and unread rows are left out).  (1) In the block of the TOP tap the
+  // incoming gradient is zero on token rows < ph0 (dtaps above; the MLP branch is row-wise), so dO is: those queries add nothing to
+  // dK / dV and their dq is zero.  (2) Block 0 feeds the patch-embed dgrad of the prompt half only (EPI_UNPATCH below reads the top
+  // N / 2 tokens): dq / dk / dv of the query half are never read.  dQ still publishes the softmax tables of every query.
+  const int zero_tokens = (first_row > 0 ? (first_row - 1) / 16 : 0) * wp;
   for (int l = L - 1; l >= 0; --l) {
     int ti;
+    const bool top_block = !dx_valid;
     if (m->is_tap(l, &ti)) {  // d/dx of the shared tap LayerNorm applied to x_in[l+1]  (HF:475-476)
       ln_bwd<T>(c, dtaps + (long)ti * D, (long)nt * D, c.template at<float>("x_in", l + 1), m->gw(4), dx_valid ? dx : nullptr, dx,
                 dx_t_out, rows);
@@ -603,13 +622,16 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       a.q = qkv; a.k = qkv + D; a.v = qkv + 2 * D; a.ld = 3 * D; a.kt = kt; a.dout = dn_b; a.ldo = D; a.rel_cat = m->lw(l, 18);
       a.rel_catT = m->lw(l, 19); a.relhT = relhT; a.relwT = relwT; a.lse2 = c.template at<float>("lse2", l); a.delta = delta; a.out = (void*)attn_o; a.dq = dqkv;
       a.S = B; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = scale;
+      a.dq_begin = top_block ? zero_tokens / 128 * 128 : 0;
+      a.dq_end = l == 0 ? std::min(N, (N / 2 + 127) / 128 * 128) : 0;
+      const double dq_frac = (double)((a.dq_end ? a.dq_end : N) - a.dq_begin) / N;
       static bool once = (allow_lds(attn_bwd_dq_kernel<T, tr>, 160 * 1024), true);
       (void)once;
       {
         // ALGORITHMIC work of the attention backward (SURVEY.md section 8 d): 2 x the forward's matmuls = 8 N^2 d per head, credited
         // half to each of the two kernels that share it.  (They EXECUTE 6 + 8 = 14 N^2 d: both recompute S and dP; a one-pass
         // flash backward executes 10.  Rounds 1-3 credited the executed count, which flattered both kernels by 1.75x.)
-        ProfScope ps(m, st, PC_ATTN_BWD_DQ, 4.0 * B * nh * (double)N * N * 64);
+        ProfScope ps(m, st, PC_ATTN_BWD_DQ, 4.0 * B * nh * (double)N * N * 64 * dq_frac);
         const dim3 qgrid(((N + 127) / 128) * nh * B);
         const int relh_lds = 4 * 32 * (hp | 1) * 4;
         bool x3_done = false;
@@ -628,8 +650,11 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.k = qkv + D; k.v = qkv + 2 * D; k.q = qkv; k.dout = dn_b; k.qt = qt; k.dot = dot; k.ld = 3 * D; k.ldo = D;
       k.relwT = relwT; k.relhT = relhT; k.lse2 = a.lse2; k.delta = delta; k.dk = dqkv + D; k.dv = dqkv + 2 * D;
       k.S = B; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = scale;
+      k.q_begin = top_block ? zero_tokens / 64 * 64 : 0;
+      k.key_rows = l == 0 ? (hp + 1) / 2 : 0;
       {
-        ProfScope ps(m, st, PC_ATTN_BWD_DKV, 4.0 * B * nh * (double)N * N * 64);
+        // (credited as if the windows applied; the kernels that ignore them -- f32, token grids the four-wave form does not take -- do more)
+        ProfScope ps(m, st, PC_ATTN_BWD_DKV, 4.0 * B * nh * (double)N * N * 64 * ((double)(N - k.q_begin) / N) * (k.key_rows ? (double)k.key_rows / hp : 1.0));
         launch_dkv<T>(k, st, m->c.gemm_x3 != 0);
       }
       CHECK_LAUNCH();
@@ -762,14 +787,22 @@ int bsg_workspace_region(const bsg_model* m, int batch, int train, const char* n
 int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
                 const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace, size_t workspace_bytes,
                 int save_for_backward) {
+  return bsg_forward_rows(m, stream, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, 0, pred_masks, workspace,
+                          workspace_bytes, save_for_backward);
+}
+
+int bsg_forward_rows(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
+                     const float* prompt_masks, int embedding_type, int first_row, float* pred_masks, void* workspace,
+                     size_t workspace_bytes, int save_for_backward) {
   if (!m || !pixel_values || !prompt_pixel_values || !prompt_masks || !pred_masks || !workspace) return fail("bsg_forward: null argument");
+  if (first_row < 0 || first_row >= m->c.canvas_h) return fail("first_row %d outside the canvas", first_row);
   if (batch <= 0) return fail("batch must be positive");
   if (embedding_type != 0 && embedding_type != 1)
     return fail("Embedding type should be either 'semantic' or 'instance', but got %d", embedding_type);
   if (workspace_bytes < bsg_workspace_bytes(m, batch, save_for_backward))
     return fail("workspace too small: %zu < %zu", workspace_bytes, bsg_workspace_bytes(m, batch, save_for_backward));
   hipStream_t st = (hipStream_t)stream;
-#define BSG_FWD(TT) forward_impl<TT>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward)
+#define BSG_FWD(TT) forward_impl<TT>(m, st, batch, pixel_values, prompt_pixel_values, prompt_masks, embedding_type, pred_masks, workspace, save_for_backward, 0, first_row)
   return m->c.dtype == BSG_DTYPE_F32 ? BSG_FWD(float) : m->c.dtype == BSG_DTYPE_BF16 ? BSG_FWD(bf16_t) : BSG_FWD(f16_t);
 #undef BSG_FWD
 }

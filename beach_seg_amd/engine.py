@@ -120,9 +120,11 @@ class PromptTrainEngine:
         B = self._last_batch = pixel_values.shape[0]
         self._flat.zero_()
         prompts = ops.prompt_gather(self.params, prompt_idx)  # stack + Normalize
-        pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True)
+        half = m.geometry.image_size[0] // 2
+        # SegGptLoss reads the query half of the prediction (`src/model.py:53-57`): the decoder runs over those rows only
+        pred = m._run_forward(pixel_values, prompts, prompt_mask_color, 0, train=True, first_row=half)
         loss, gpred = loss_and_grad(pred)
-        gpix = m._run_backward(gpred, B, first_row=pred.shape[2] // 2)  # the loss gradient is zero on the prompt half
+        gpix = m._run_backward(gpred, B, first_row=half)  # ... and the loss gradient is zero on the prompt half
         ops.prompt_grad_scatter(gpix, prompt_idx, self.grads)
         self._touched_f.index_fill_(0, prompt_idx.long(), 1.0)
         if m.dtype == torch.float16 or getattr(m, "gemm_x3", False):  # device-side overflow guard of the scaled dgrad chain (no host sync)

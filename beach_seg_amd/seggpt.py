@@ -298,13 +298,15 @@ class SegGptNative(torch.nn.Module):
         return out
 
     def _run_forward(self, pix, prm, pmask, emb: int, train: bool, ensemble: bool = False,
-                     ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     ws: Optional[torch.Tensor] = None, first_row: int = 0) -> torch.Tensor:
         """`ws` None: the fused-engine convention -- a free workspace of this shape, remembered as `_last_ws` for the
-        `_run_backward` that follows immediately (no autograd node involved)."""
+        `_run_backward` that follows immediately (no autograd node involved).  `first_row` > 0 (`bsg_forward_rows`): the
+        caller reads the prediction on canvas rows >= first_row only; the rows above the first computed 16-row tile come
+        back as zeros."""
         B = pix.shape[0]
         H, W = self.geometry.image_size
         pix, prm, pmask = (t.to(self._device, torch.float32).contiguous() for t in (pix, prm, pmask))
-        pred = torch.empty((B, 3, H, W), dtype=torch.float32, device=self._device)
+        pred = (torch.zeros if first_row else torch.empty)((B, 3, H, W), dtype=torch.float32, device=self._device)
         if ws is None:
             ws = self._free_train_workspace(B) if train else self.workspace(B, False)
         with torch.cuda.device(self._device):
@@ -312,8 +314,8 @@ class SegGptNative(torch.nn.Module):
                 N.check(self._lib.bsg_forward_ensemble(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb,
                                                        _ptr(pred), _ptr(ws), ws.numel()))
             else:
-                N.check(self._lib.bsg_forward(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb, _ptr(pred),
-                                              _ptr(ws), ws.numel(), int(train)))
+                N.check(self._lib.bsg_forward_rows(self._h, _stream(), B, _ptr(pix), _ptr(prm), _ptr(pmask), emb, int(first_row),
+                                                   _ptr(pred), _ptr(ws), ws.numel(), int(train)))
         self._last_ws = ws if train else None
         return pred
 

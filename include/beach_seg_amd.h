@@ -91,6 +91,16 @@ int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values
                 const float* prompt_masks, int embedding_type, float* pred_masks, void* workspace,
                 size_t workspace_bytes, int save_for_backward);
 
+/* The same forward for a caller that reads pred_masks on canvas rows >= first_row only -- the fused train step: the
+ * reference's loss and its decode of the prediction cover the query half (src/model.py:53-57, process_pred_masks), so
+ * first_row = H/2 there.  The encoder runs in full; the decoder (tap LayerNorms, decoder_embed, 3x3 conv, head) runs over the
+ * token rows that reach those pixels and, with save_for_backward, the ones bsg_backward_rows(first_row) reads back.  Rows of
+ * pred_masks above the first computed 16-row tile are NOT written.  first_row = 0 is bsg_forward; the rows that are written
+ * hold the same bits as bsg_forward's.  A following backward must be bsg_backward_rows with a first_row >= this one. */
+int bsg_forward_rows(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
+                     const float* prompt_masks, int embedding_type, int first_row, float* pred_masks, void* workspace,
+                     size_t workspace_bytes, int save_for_backward);
+
 /* The same forward with feature_ensemble=True (HF:414-423; the few-shot caller src/predict_no_prompt.py:283-304): the
  * `batch` rows are K prompts for ONE query; in every block the query-half of the attention-block output is replaced
  * by its mean over the prompts (per stream kind before the merge block, over all rows from the merge block on).

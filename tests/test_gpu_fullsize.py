@@ -2,7 +2,7 @@
 sizes through size-independent properties and against the oracle pipeline.
 
 * BASELINE configs[1] (ViT-L, bf16, B=64 train step): the exact call sequence of `PromptTrainEngine.step` --
-  `bsg_forward(save)` -> `bsg_loss_fwd_bwd` -> `bsg_backward_rows(first_row = H/2)` -- at B=64, where the persistent
+  `bsg_forward[_rows](save)` -> `bsg_loss_fwd_bwd` -> `bsg_backward_rows(first_row = H/2)` -- at B=64, where the persistent
   GEMM grid, the tail-split 128^2 launches and the row-windowed decoder backward are live.  A sample's prediction and
   prompt gradient must be BIT-identical to what the same sample gives alone (B=1), and the row-windowed backward must
   equal the plain one.
@@ -51,6 +51,13 @@ def test_vit_large_b64_engine_call_sequence_matches_b1_bit_for_bit():
     assert torch.equal(g_rows, g_full), float((g_rows - g_full).abs().max())
     g_real = model._run_backward(g_loss, B, first_row=Hh)                          # the engine's own gradient: finite, non-zero
     assert torch.isfinite(g_real).all() and float(g_real.abs().max()) > 0
+    # bsg_forward_rows(first_row = H/2), what the engine calls: the decoder over the query half (+ what the backward reads back);
+    # the rows it writes hold the bits of the full forward, and the backward that follows gives the same gradient
+    pred_w = model._run_forward(pix, prm, pmask, 0, train=True, first_row=Hh)
+    assert torch.equal(pred_w[:, :, Hh:], pred[:, :, Hh:])
+    assert float(pred_w[:, :, :Hh - 32].abs().max()) == 0.0                        # rows above the first computed 16-row tile: not written
+    g_w = model._run_backward(gpred, B, first_row=Hh)
+    assert torch.equal(g_w, g_rows), float((g_w - g_rows).abs().max())
     for i in (0, 37, 63):
         p1 = model._run_forward(pix[i:i + 1], prm[i:i + 1], pmask[i:i + 1], 0, train=True)
         assert torch.equal(p1[0], pred[i]), f"sample {i}: prediction depends on the batch"

@@ -219,6 +219,32 @@ def test_x3_mode_engine_step_tracks_exact_f32():
         SegGptNative(sd, geo, device=DEV, dtype=torch.bfloat16, gemm_x3=True)
 
 
+@pytest.mark.parametrize("dtype,x3", [(torch.bfloat16, False), (torch.float16, False), (torch.float32, False), (torch.float32, True)])
+def test_forward_rows_window_holds_the_bits_of_the_full_forward(dtype, x3):
+    """`bsg_forward_rows(first_row = H/2)` -- the fused engine's forward: the decoder runs over the query half (plus the rows
+    `bsg_backward_rows` reads back) -- against `bsg_forward` on the same inputs, every dtype: the written rows are bit-identical,
+    the rows above the first computed tile are not touched, and the backward that follows gives the same prompt gradient."""
+    geo = SegGptGeometry.tiny()
+    net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=dtype, gemm_x3=x3)
+    H, W = geo.image_size
+    g = torch.Generator().manual_seed(11)
+    B = 3
+    pix, prm, pm = (torch.randn(B, 3, H // 2, W, generator=g).to(DEV) for _ in range(3))
+    gpred = torch.zeros(B, 3, H, W, device=DEV)
+    gpred[:, :, H // 2:] = torch.randn(B, 3, H // 2, W, generator=g).to(DEV) * 1e-3
+    full = net._run_forward(pix, prm, pm, 0, train=True)
+    g_full = net._run_backward(gpred, B, first_row=H // 2)
+    win = net._run_forward(pix, prm, pm, 0, train=True, first_row=H // 2)
+    g_win = net._run_backward(gpred, B, first_row=H // 2)
+    assert torch.equal(win[:, :, H // 2:], full[:, :, H // 2:])
+    first_tile = max(0, 16 * ((H // 2 - 1) // 16) - 8) // 16 * 16
+    assert first_tile > 0 and float(win[:, :, :first_tile].abs().max()) == 0.0
+    assert torch.equal(win[:, :, first_tile:], full[:, :, first_tile:])
+    assert torch.isfinite(g_win).all() and float(g_win.abs().max()) > 0 and torch.equal(g_win, g_full)
+    with pytest.raises(RuntimeError):
+        net._run_forward(pix, prm, pm, 0, train=True, first_row=H)
+
+
 def test_validation_forward_and_predict_mosaic():
     geo = SegGptGeometry.tiny()
     net = SegGptNative(synth_state_dict(geo, seed=1), geo, device=DEV, dtype=torch.float32)
