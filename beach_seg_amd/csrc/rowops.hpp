@@ -8,13 +8,15 @@
 // ---------------------------------------------------------------------------------------------- LayerNorm
 // one wave per row; x fp32 [rows][D], D <= 2048; y = T [rows][ldy] (column offset applied by the caller).
 // Branch-free: lanes past D load column 0 and contribute zeros.
-struct LnRow {
-  f32x4 v[8];
+// NV = 16-byte pieces per lane: 4 covers D <= 1024 (ViT-L), 8 covers D <= 2048 (the loads past D used to be issued and masked:
+// at D = 1024 that was every second load instruction of these kernels)
+template <int NV> struct LnRow {
+  f32x4 v[NV];
   float mean, rstd;
   DEVI void load(const float* xr, int lane, int D, float eps) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       const bool ok = c < D;
       const f32x4 t = *(const f32x4*)(xr + (ok ? c : 0));
@@ -24,7 +26,7 @@ struct LnRow {
     mean = wave_sum(s) / D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const bool ok = (i * 64 + lane) * 4 < D;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -36,7 +38,7 @@ struct LnRow {
   }
 };
 
-template <typename T>
+template <typename T, int NV = 8>
 __global__ __launch_bounds__(256, 4) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, T* __restrict__ y, long ldy,
                                                          int rows, int D, float eps, int in_rpg = 0, long in_gstride = 0,
@@ -46,11 +48,11 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_kernel(const float* __restrict_
   // in_rpg > 0: output row r (compact) reads input row (r / in_rpg) * in_gstride + in_off + r % in_rpg -- the row window of
   // every stream gathered into consecutive rows (the decoder's tap LayerNorms under bsg_forward_rows)
   const long xrow = in_rpg ? (long)(row / in_rpg) * in_gstride + in_off + row % in_rpg : row;
-  LnRow r;
+  LnRow<NV> r;
   r.load(x + xrow * D, lane, D, eps);
   T* yr = y + (long)row * ldy;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
@@ -63,20 +65,20 @@ __global__ __launch_bounds__(256, 4) void ln_fwd_kernel(const float* __restrict_
 
 // dx[row] = dx_in[row] * in_scale + LN'(x[row]) applied to dy[row]; optional T copy for the next dgrad GEMM.
 // Statistics are recomputed from x (read anyway), nothing is saved by the forward.
-template <typename T>
+template <typename T, int NV = 8>
 __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                          const float* __restrict__ gamma, const float* dx_in,
                                                          float in_scale, float* dx_out, T* dx_t, int rows, int D,
                                                          float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
-  LnRow r;
+  LnRow<NV> r;
   r.load(x + (long)row * D, lane, D, eps);
   const T* dyr = dy + (long)row * lddy;
-  f32x4 g[8];
+  f32x4 g[NV];
   float sg = 0.f, sgx = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     const bool ok = c < D;
     const typename Traits<T>::Vec4 d = *(const typename Traits<T>::Vec4*)(dyr + (ok ? c : 0));
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256, 4) void ln_bwd_kernel(const T* __restrict__ dy
   }
   const float mg = wave_sum(sg) / D, mgx = wave_sum(sgx) / D;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < D) {
       f32x4 o;
