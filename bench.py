@@ -165,22 +165,21 @@ def csrc_sha() -> str:
 PMC_SUMMARY = ROOT / "profiles" / "r4_pmc_summary.json"
 
 
-def gemm_hbm_traffic_per_launch() -> tuple[float | None, str]:
+def gemm_hbm_traffic_per_launch(launches_per_step: float) -> tuple[float | None, str]:
     """HBM bytes per GEMM launch (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction) from the committed rocprofv3 --pmc
     summary of this same command (`tools/pmc_summary.py`): PMC passes cannot run inside the timed process, so the
-    figure is measured offline.  The summary records the hash of the kernel sources it was taken on; if the kernels
-    have changed since, the figure is stale and None is reported."""
+    figure is measured offline.  A "launch" is what `roofline.avg_launch_ms` times -- one GEMM of the step, i.e. the 256 x 256
+    kernel together with its 128 x 128 tail launch where it has one: all GEMM-family bytes of a step / `launches_per_step`.
+    The summary records the hash of the kernel sources it was taken on; if the kernels have changed since, the figure is stale
+    and None is reported."""
     if not PMC_SUMMARY.exists():
         return None, "no PMC summary committed"
     d = json.loads(PMC_SUMMARY.read_text())
     meta = d.get("_meta", {})
     if meta.get("csrc_sha") != csrc_sha():
         return None, f"PMC summary {PMC_SUMMARY.name} was taken on kernels {meta.get('csrc_sha')}, current {csrc_sha()}: stale"
-    n = b = 0.0
-    for k, v in d.items():
-        if "gemm_nt_kernel" in k:
-            n += v["launches"]
-            b += v["launches"] * (v["hbm_fetch_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6
+    b = sum(v["launches"] * (v["hbm_fetch_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6 for k, v in d.items() if "gemm_nt" in k)
+    n = meta.get("steps", 3) * launches_per_step
     return (round(b / n) if n else None), f"{PMC_SUMMARY.name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, offline pass, kernels {meta.get('csrc_sha')})"
 
 
@@ -350,7 +349,7 @@ def main() -> None:
         if prof is not None:
             ms, fl, n = prof["gemm"]
             achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            traffic, traffic_src = gemm_hbm_traffic_per_launch() if (args.batch == 64 and args.dtype == "bf16") else (None, "n/a")
+            traffic, traffic_src = gemm_hbm_traffic_per_launch(n / nprof) if (args.batch == 64 and args.dtype == "bf16") else (None, "n/a")
             out["roofline"] = {
                 "kernel": "gemm_nt_kernel (all epilogues)", "bound": "mfma", "achieved": round(achieved, 1), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -53,6 +53,7 @@ for k in sd:
                   "valu_insts_per_mfma": (ia[k]["SQ_INSTS_VALU"] - mf) / mf if mf else None,
                   "lds_insts_per_mfma": ia[k]["SQ_INSTS_LDS"] / mf if mf else None})
     o["hbm_GBps"] = (o["hbm_fetch_MB_per_launch"] + o["hbm_write_MB_per_launch"]) * 1e6 / (o["avg_us"] * 1e3) if o["avg_us"] else 0
-out["_meta"] = {"csrc_sha": csrc_sha(), "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE x1; one rocprofv3 --pmc pass per counter group"}
+out["_meta"] = {"csrc_sha": csrc_sha(), "steps": 3,  # tools/profile_run.sh profiles `bench.py --steps 2 --warmup 1`
+                "note": "FETCH_SIZE x2 (gfx950 wide-read correction), WRITE_SIZE x1; one rocprofv3 --pmc pass per counter group"}
 json.dump(out, open(sys.argv[5], "w"), indent=1)
 print("wrote", sys.argv[5], len(out), "kernels")
