@@ -291,3 +291,23 @@ def test_sharded_accumulator_refuses_votes_after_the_rank_sum():
         acc.update("d0", torch.zeros(0, 4, dtype=torch.int32), torch.zeros(0, 2, 2, dtype=torch.uint8), 2)
     acc.initialize_current("d1")
     assert acc._reduced is False
+
+
+def test_bench_flop_counts_reference_and_executed():
+    """`bench.py` prices utilisation on the FLOPs the fused step executes: the reference's count (SURVEY.md section 8 d: 1589.7 +
+    1678.3 GF per ViT-L tile) minus the decoder / attention-backward rows that only feed the unread prompt half of the prediction
+    (`bsg_forward_rows` / `bsg_backward_rows`, window formulas of `seggpt_api.hip`)."""
+    import bench
+    from beach_seg_amd.weights import SegGptGeometry
+
+    g = SegGptGeometry.vit_large()
+    fwd, bwd = bench.flops_per_tile(g)
+    assert abs(fwd / 1e9 - 1589.7) < 0.1 and abs(bwd / 1e9 - 1678.3) < 0.1
+    ex = bench.executed_flops_per_tile(g)
+    dec = 2.0 * 1568 * 4096 * 16384
+    conv, head, att = 2.0 * 896 * 448 * 9 * 64 * 64, 2.0 * 896 * 448 * 64 * 3, 4.0 * 1568 * 1568 * 1024
+    want = fwd + bwd - dec * (25 + 27) / 56 - (conv + head) * 416 / 896 - conv * 432 / 896 - head * 424 / 896 \
+        - att * (640 + 704) / 1568 - att * ((1568 - 896) / 1568 + 0.5)
+    assert abs(ex - want) < 1e6 and 0.90 < ex / (fwd + bwd) < 0.95
+    g5 = SegGptGeometry.config5()
+    assert bench.executed_flops_per_tile(g5) < sum(bench.flops_per_tile(g5))
