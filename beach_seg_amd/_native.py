@@ -28,7 +28,7 @@ SYMBOLS = (
     "bsg_create", "bsg_destroy", "bsg_workspace_bytes", "bsg_workspace_region", "bsg_forward", "bsg_backward",
     "bsg_loss_scratch_bytes", "bsg_loss_fwd_bwd", "bsg_decode_argmin", "bsg_prompt_gather",
     "bsg_prompt_grad_scatter", "bsg_adamw_step", "bsg_vote_paste", "bsg_vote_argmax", "bsg_last_error",
-    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_op_gemm_epilogue", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_forward_rows", "bsg_tile_frontend", "bsg_decode_hf",
+    "bsg_build_info", "bsg_profile_enable", "bsg_profile_read", "bsg_profile_reset", "bsg_op_gemm", "bsg_op_gemm_epilogue", "bsg_forward_ensemble", "bsg_backward_rows", "bsg_forward_rows", "bsg_op_attention_windows", "bsg_tile_frontend", "bsg_decode_hf",
     "bsg_op_attention", "bsg_op_attention_scratch_bytes", "bsg_tif_image", "bsg_train_aug", "bsg_train_aug_bwd",
     "bsg_confusion_update", "bsg_loss_fwd_bwd_ids", "bsg_mask_rgb_norm",
 )
@@ -104,6 +104,7 @@ def load():
     lib.bsg_op_attention_scratch_bytes.argtypes = [i, i, i]
     lib.bsg_op_attention_scratch_bytes.restype = sz
     lib.bsg_op_attention.argtypes = [vp, i, i, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz]
+    lib.bsg_op_attention_windows.argtypes = [i, i, i, i]
     _lib = lib
     return lib
 

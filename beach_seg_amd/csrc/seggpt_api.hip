@@ -1006,6 +1006,8 @@ static int op_gemm_epilogue_impl(hipStream_t st, int epilogue, int M, int N, int
   return 0;
 }
 
+// bsg_op_attention_windows: the row windows the NEXT bsg_op_attention call of this thread runs its backward kernels with
+static thread_local int g_attn_win[4] = {0, 0, 0, 0};  // dq_begin, dq_end, q_begin, key_rows
 template <typename T>
 static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int wp, const void* qkv, const void* rel_cat,
                              const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
@@ -1038,6 +1040,7 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     a.q = q; a.k = q + D; a.v = q + 2 * D; a.ld = 3 * D; a.dout = dout; a.ldo = D; a.rel_cat = rel_cat; a.rel_catT = rel_catT;
     a.relhT = relhT; a.relwT = relwT; a.lse2 = lse2; a.delta = delta; a.out = out; a.dq = dqkv;
     a.S = S; a.nh = nh; a.N = N; a.hp = hp; a.wp = wp; a.scale = 0.125f;
+    a.dq_begin = g_attn_win[0]; a.dq_end = g_attn_win[1];
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), dim3(((N + 127) / 128) * nh * S), dim3(256),
                        4 * AttnK<T>::TILE + relh_lds, st, a);
     CHECK_LAUNCH();
@@ -1058,9 +1061,11 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
     k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
     k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    k.q_begin = g_attn_win[2]; k.key_rows = g_attn_win[3];
     launch_dkv<T>(k, st);
     CHECK_LAUNCH();
   }
+  g_attn_win[0] = g_attn_win[1] = g_attn_win[2] = g_attn_win[3] = 0;
   if (which & 16) {  // A/B: the eight-wave dK / dV kernel (one workgroup per CU)
     AttnBwdKvArgs k{};
     k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
@@ -1089,6 +1094,11 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
 }
 
 extern "C" {
+int bsg_op_attention_windows(int dq_begin, int dq_end, int q_begin, int key_rows) {
+  if (dq_begin < 0 || dq_end < 0 || q_begin < 0 || q_begin % 64 || key_rows < 0) return fail("bsg_op_attention_windows: bad window");
+  g_attn_win[0] = dq_begin; g_attn_win[1] = dq_end; g_attn_win[2] = q_begin; g_attn_win[3] = key_rows;
+  return 0;
+}
 int bsg_op_gemm_epilogue(void* stream, int dtype, int epilogue, int M, int N, int K, const void* A, const void* W, const float* bias,
                          const void* aux, void* out, void* out2) {
   if (!A || !W || !out) return fail("bsg_op_gemm_epilogue: null argument");

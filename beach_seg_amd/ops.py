@@ -350,15 +350,19 @@ def attention_scratch(S: int, nh: int, hp: int, device) -> torch.Tensor:
 
 def attention(which: int, qkv: torch.Tensor, rel_cat: torch.Tensor, S: int, nh: int, hp: int, wp: int, out: torch.Tensor,
               lse2: torch.Tensor, scratch: torch.Tensor, rel_catT: torch.Tensor | None = None,
-              dout: torch.Tensor | None = None, dqkv: torch.Tensor | None = None) -> None:
+              dout: torch.Tensor | None = None, dqkv: torch.Tensor | None = None,
+              windows: tuple[int, int, int, int] | None = None) -> None:
     """The fused attention kernels on their own (`bsg_op_attention`): bit 0 forward, bit 1 dQ, bit 2 dK/dV (bits 3-5: its A/B
     variants, see the header).  bf16 or f16 tensors:
-    qkv (S*N, 3*nh*64), rel_cat ([LH+LW], 64) / rel_catT, dout / out (S*N, nh*64), dqkv like qkv; lse2 f32 (S, nh, hp*32)."""
+    qkv (S*N, 3*nh*64), rel_cat ([LH+LW], 64) / rel_catT, dout / out (S*N, nh*64), dqkv like qkv; lse2 f32 (S, nh, hp*32).
+    `windows` = (dq_begin, dq_end, q_begin, key_rows): the row windows of `bsg_backward_rows` for this call (header)."""
     _need_gpu(qkv, rel_cat, out, lse2, scratch)
     lib = N.load()
     with torch.cuda.device(qkv.device):
         if qkv.dtype not in (torch.bfloat16, torch.float16):
             raise ValueError("the stand-alone attention entry takes bfloat16 or float16 tensors")
+        if windows is not None:
+            N.check(lib.bsg_op_attention_windows(*(int(v) for v in windows)))
         N.check(lib.bsg_op_attention(_stream(), _DTYPE_CODE[qkv.dtype], which, S, nh, hp, wp, _ptr(qkv), _ptr(rel_cat), _ptr(rel_catT), _ptr(dout),
                                      _ptr(out), _ptr(lse2), _ptr(dqkv), _ptr(scratch), scratch.numel()))
 

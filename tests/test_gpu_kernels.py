@@ -152,3 +152,47 @@ def test_attention_kernels_vs_torch(hp, wp, S, nh, gain, dtype):
             assert rel(ref[:, :D], gk) < 1.5e-2 and rel(ref[:, D:], gv) < 1.5e-2
         assert torch.equal(dqkv[:, D:], ref), f"dK / dV variant bit {bit} differs from the one-wave-per-SIMD kernel"
     del want
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hp,wp,S,nh", [(56, 28, 2, 2), (64, 32, 1, 1)])
+def test_attention_backward_row_windows_are_exact(hp, wp, S, nh, dtype):
+    """The row windows of `bsg_backward_rows` at kernel level (`bsg_op_attention_windows`), against the same kernels without
+    them, bit for bit.  (1) Top tap's block: dO is exactly zero on the first token rows -- dQ workgroups wholly below
+    `dq_begin` return zero rows (which is what the full kernel computes there), dK / dV streams the queries from `q_begin` on
+    and gets the same sums.  (2) Block 0: dq for the queries below `dq_end`, dK / dV for the first Hp / 2 key rows only -- the
+    wanted rows carry the same bits, the others are zero (dq) or not written (dk, dv)."""
+    N, D = hp * wp, nh * 64
+    g = torch.Generator(device=DEV).manual_seed(hp + wp)
+    qkv = (torch.randn(S * N, 3 * D, device=DEV, generator=g) * 0.8).to(dtype)
+    dout = (torch.randn(S * N, D, device=DEV, generator=g) * (1e-3 if dtype == torch.bfloat16 else 1.0)).to(dtype)
+    rel_h = torch.randn(2 * hp - 1, 64, device=DEV, generator=g) * 0.2
+    rel_w = torch.randn(2 * wp - 1, 64, device=DEV, generator=g) * 0.2
+    rc = _rel_cat(rel_h, rel_w).to(dtype).contiguous()
+    rcT = rc.t().contiguous()
+    out = torch.empty(S * N, D, device=DEV, dtype=dtype)
+    lse2 = torch.zeros(S, nh, hp * 32, device=DEV)
+    scratch = ops.attention_scratch(S, nh, hp, DEV)
+    run = lambda which, do, dqkv, win=None: ops.attention(which, qkv, rc, S, nh, hp, wp, out, lse2, scratch, rcT, do, dqkv, windows=win)
+    run(1, dout, torch.zeros_like(qkv))
+    # (1) zero dO on the token rows above row 27 / 31 of the grid
+    zero_tok = (hp // 2 - 1) * wp
+    dz = dout.clone().reshape(S, N, D)
+    dz[:, :zero_tok] = 0
+    dz = dz.reshape(S * N, D)
+    full, win = torch.zeros_like(qkv), torch.full_like(qkv, 7.0)
+    run(6, dz, full)
+    run(6, dz, win, (zero_tok // 128 * 128, 0, zero_tok // 64 * 64, 0))
+    assert torch.equal(win, full)
+    assert float(full.reshape(S, N, 3 * D)[:, :zero_tok, :D].abs().max()) == 0.0  # the premise: dq of a query with zero dO is zero
+    # (2) the prompt half only
+    q_end, key_rows = min(N, (N // 2 + 127) // 128 * 128), hp // 2
+    full = torch.zeros_like(qkv)
+    run(6, dout, full)
+    win = torch.full_like(qkv, 7.0)
+    run(6, dout, win, (0, q_end, 0, key_rows))
+    f3, w3 = full.reshape(S, N, 3 * D), win.reshape(S, N, 3 * D)
+    assert torch.equal(w3[:, :q_end, :D], f3[:, :q_end, :D]) and float(w3[:, q_end:, :D].abs().max()) == 0.0
+    assert torch.equal(w3[:, :key_rows * wp, D:], f3[:, :key_rows * wp, D:])
+    assert bool((w3[:, key_rows * wp:, D:] == 7.0).all())  # not written
+    assert torch.isfinite(win.float()).all()
