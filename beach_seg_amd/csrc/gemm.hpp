@@ -347,48 +347,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // workgroups on 256 CUs -- one per CU, nothing else resident -- so the two-stage kernel above paid a full HBM round trip per
 // K tile (measured 17 / 61 us at K = 1024 / 4096 where the MFMAs need 4 / 16).  The DMA is the asm form: hipcc drains the
 // builtin one before the next LDS read.
-template <typename T, int EPI>
+// TMT = rows of the tile (columns: 128).  128: four waves of 64 x 64.  64: four waves of 32 x 64 -- twice the workgroups, for tails
+// that would otherwise leave half of the CUs idle (2,048 rows x 1,024 columns = 128 tiles of 128 x 128, 256 of 64 x 128).
+template <typename T, int EPI, int TMT = 128>
 __global__ __launch_bounds__(256, 1) void gemm_nt_tail_kernel(GemmArgs g) {
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BK = 8 * EPC;  // elements per 128-byte K tile
-  constexpr int NS = 4, STAGE = 32768;  // [stage][A 128 rows x 128 B | W 128 rows x 128 B]
+  constexpr int NS = 4, ABYTES = TMT * 128, STAGE = ABYTES + 16384;  // [stage][A TMT rows x 128 B | W 128 rows x 128 B]
+  constexpr int NA = TMT / 32, MI = TMT / 32;  // A pieces (8 rows x 128 B) per wave and stage; 16-row fragments per wave tile
+  constexpr int PIECES = NA + 4;               // LDS-DMA instructions per wave and stage
   typedef typename Traits<T>::Chunk Chunk;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (g.N + 127) >> 7, tiles_m = (g.M + 127) >> 7;
+  const int tiles_n = (g.N + 127) >> 7, tiles_m = (g.M + TMT - 1) / TMT;
   const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
-  const int m0 = tm << 7, n0 = tn << 7;
+  const int m0 = tm * TMT, n0 = tn << 7;
 
   const int prow = lane >> 3, pchunk = lane & 7;
-  const char* a_src[4];
+  const char* a_src[NA];
   const char* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (i < NA) {
+      const int r = (wave * NA + i) * 8 + prow;
+      int m = m0 + r;
+      if (m >= g.M) m = g.M - 1;
+      a_src[i] = (const char*)g.A + ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda * sizeof(T) + ((pchunk ^ (r & 7)) << 4);
+    }
     const int r = (wave * 4 + i) * 8 + prow;
-    const int sc = pchunk ^ (r & 7);
-    int m = m0 + r;
-    if (m >= g.M) m = g.M - 1;
-    a_src[i] = (const char*)g.A + ((long)(m / g.a_rpg) * g.a_gstride + (m % g.a_rpg)) * g.lda * sizeof(T) + sc * 16;
     int n = n0 + r;
     if (n >= g.N) n = g.N - 1;
-    w_src[i] = (const char*)g.W + (long)n * g.K * sizeof(T) + sc * 16;
+    w_src[i] = (const char*)g.W + (long)n * g.K * sizeof(T) + ((pchunk ^ (r & 7)) << 4);
   }
   auto stage = [&](int kt) {
     const long k0 = (long)kt * BK * sizeof(T);
-    char* la = smem + (kt & (NS - 1)) * STAGE + wave * 4096;
+    char* ls = smem + (kt & (NS - 1)) * STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16_asm(a_src[i] + k0, la + i * 1024);
-      glds16_asm(w_src[i] + k0, la + 16384 + i * 1024);
+      if (i < NA) glds16_asm(a_src[i] + k0, ls + (wave * NA + i) * 1024);
+      glds16_asm(w_src[i] + k0, ls + ABYTES + (wave * 4 + i) * 1024);
     }
   };
 
   const int wr = wave >> 1, wc = wave & 1;
   const int frow = lane & 15, fchunk = lane >> 4;
-  f32x4 acc[4][4];  // [ni][mi]
+  f32x4 acc[4][4];  // [ni][mi], mi < MI
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -398,32 +404,34 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_tail_kernel(GemmArgs g) {
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) stage(s);
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when at most the 8 pieces of each younger tile are outstanding (vmcnt retires in order)
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // tile kt has landed when at most the PIECES of each younger tile are outstanding (vmcnt retires in order)
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PIECES) : "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIECES) : "memory");
     else wait_vm0();
     __syncthreads();  // ... for every wave's pieces; and every wave is done reading tile kt - 1, whose stage is refilled now
     if (kt + NS - 1 < nk) stage(kt + NS - 1);
     const char* la = smem + (kt & (NS - 1)) * STAGE;
-    const char* lw = la + 16384;
+    const char* lw = la + ABYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Chunk fa[4], fw[4];
+      Chunk fa[MI], fw[4];
+      const int c = fchunk + 4 * ks;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + frow;
+        if (i < MI) {
+          const int ra = wr * (TMT / 2) + i * 16 + frow;
+          fa[i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+        }
         const int rw = wc * 64 + i * 16 + frow;
-        const int c = fchunk + 4 * ks;
-        fa[i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
         fw[i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
+        for (int mi = 0; mi < MI; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
     }
   }
-  gemm_epilogue<T, EPI>(g, acc, m0 + wr * 64, n0 + wc * 64, frow, fchunk);
+  gemm_epilogue<T, EPI, MI>(g, acc, m0 + wr * (TMT / 2), n0 + wc * 64, frow, fchunk);
 }
 
 // ------------------------------------------------------------------------------------------------------------

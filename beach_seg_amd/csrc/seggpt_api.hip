@@ -185,9 +185,12 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
       const int tiles_b = ((b.M + 127) / 128) * ((b.N + 127) / 128);
       if constexpr (AM == A_PLAIN) {
         if (b.K / (8 * Traits<T>::EPC) >= 3) {  // the four-stage pipeline's prologue requests three K tiles
-          static bool once_t = (allow_lds(gemm_nt_tail_kernel<T, EPI>, 131072), true);
+          static bool once_t = (allow_lds(gemm_nt_tail_kernel<T, EPI, 128>, 131072), allow_lds(gemm_nt_tail_kernel<T, EPI, 64>, 98304), true);
           (void)once_t;
-          hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI>), dim3(tiles_b, 1), dim3(256), 131072, st, b);
+          if (tiles_b <= 128)  // half of the CUs would idle: 64-row tiles, twice the workgroups
+            hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI, 64>), dim3(((b.M + 63) / 64) * ((b.N + 127) / 128), 1), dim3(256), 98304, st, b);
+          else
+            hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI, 128>), dim3(tiles_b, 1), dim3(256), 131072, st, b);
           return;
         }
       }
