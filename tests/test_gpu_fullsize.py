@@ -58,6 +58,9 @@ def test_vit_large_b64_engine_call_sequence_matches_b1_bit_for_bit():
     assert float(pred_w[:, :, :Hh - 32].abs().max()) == 0.0                        # rows above the first computed 16-row tile: not written
     g_w = model._run_backward(gpred, B, first_row=Hh)
     assert torch.equal(g_w, g_rows), float((g_w - g_rows).abs().max())
+    p1w = model._run_forward(pix[63:64], prm[63:64], pmask[63:64], 0, train=True, first_row=Hh)  # B = 1: the eight-wave GEMM with the row-window map
+    assert torch.equal(p1w[0], pred_w[63])
+    assert torch.equal(model._run_backward(gpred[63:64], 1, first_row=Hh)[0], g_rows[63])
     for i in (0, 37, 63):
         p1 = model._run_forward(pix[i:i + 1], prm[i:i + 1], pmask[i:i + 1], 0, train=True)
         assert torch.equal(p1[0], pred[i]), f"sample {i}: prediction depends on the batch"
