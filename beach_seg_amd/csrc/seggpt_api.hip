@@ -11,6 +11,8 @@
 #include <string>
 #include <type_traits>
 #include <vector>
+#include <unordered_map>
+#include <mutex>
 
 #include "../../include/beach_seg_amd.h"
 #include <algorithm>
@@ -72,6 +74,10 @@ struct bsg_model {
     return false;
   }
   int streams(int l, int B) const { return l <= c.merge_index ? 2 * B : B; }
+  // first_row of the last saving forward on each workspace: a backward over MORE rows than its forward computed would read
+  // decoder activations that were never written (bsg_forward_rows / bsg_backward_rows) -- refused, not computed
+  std::mutex fwd_rows_mu;
+  std::unordered_map<const void*, int> fwd_rows;
 };
 
 static Plan make_plan(const bsg_model* m, int B, int train) {
@@ -336,6 +342,10 @@ template <typename T> static int forward_impl(bsg_model* m, hipStream_t st, int 
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
   const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, dc = m->c.decoder_hidden;
   const float scale = 0.125f;  // head_dim^-0.5, head_dim == 64
+  if (train) {
+    std::lock_guard<std::mutex> lk(m->fwd_rows_mu);
+    m->fwd_rows[ws] = first_row;
+  }
   T* patch_a = c.template at<T>("patch_a");
   T* ln_out = c.template at<T>("ln_out");
   T* h_act = c.template at<T>("h_act");
@@ -508,6 +518,12 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
   Ctx<T> c{m, st, (char*)ws, make_plan(m, B, 1), B};
   const int N = m->N, D = m->c.hidden_size, L = m->c.num_layers, nh = m->c.num_heads, mlp = m->c.mlp_dim;
   const int hp = m->hp, wp = m->wp, nt = m->c.num_taps, H = m->c.canvas_h, W = m->c.canvas_w, dc = m->c.decoder_hidden;
+  {
+    std::lock_guard<std::mutex> lk(m->fwd_rows_mu);
+    auto it = m->fwd_rows.find(ws);
+    if (it != m->fwd_rows.end() && first_row < it->second)
+      return fail("backward over canvas rows >= %d on a workspace whose forward (bsg_forward_rows) computed rows >= %d only", first_row, it->second);
+  }
   const int rows = B * N;
   const float scale = 0.125f;
   constexpr bool kF32 = sizeof(T) == 4;

@@ -96,7 +96,8 @@ int bsg_forward(bsg_model* m, void* stream, int batch, const float* pixel_values
  * first_row = H/2 there.  The encoder runs in full; the decoder (tap LayerNorms, decoder_embed, 3x3 conv, head) runs over the
  * token rows that reach those pixels and, with save_for_backward, the ones bsg_backward_rows(first_row) reads back.  Rows of
  * pred_masks above the first computed 16-row tile are NOT written.  first_row = 0 is bsg_forward; the rows that are written
- * hold the same bits as bsg_forward's.  A following backward must be bsg_backward_rows with a first_row >= this one. */
+ * hold the same bits as bsg_forward's.  A following backward must be bsg_backward_rows with a first_row >= this one (a smaller
+ * one is refused: it would read decoder activations this forward did not write). */
 int bsg_forward_rows(bsg_model* m, void* stream, int batch, const float* pixel_values, const float* prompt_pixel_values,
                      const float* prompt_masks, int embedding_type, int first_row, float* pred_masks, void* workspace,
                      size_t workspace_bytes, int save_for_backward);

@@ -243,6 +243,11 @@ def test_forward_rows_window_holds_the_bits_of_the_full_forward(dtype, x3):
     assert torch.isfinite(g_win).all() and float(g_win.abs().max()) > 0 and torch.equal(g_win, g_full)
     with pytest.raises(RuntimeError):
         net._run_forward(pix, prm, pm, 0, train=True, first_row=H)
+    # a backward over MORE rows than the forward computed would read decoder activations that were never written: refused
+    with pytest.raises(RuntimeError, match="computed rows"):
+        net._run_backward(gpred, B, first_row=0)
+    net._run_forward(pix, prm, pm, 0, train=True)  # a full forward on the same workspace lifts it
+    assert torch.equal(net._run_backward(gpred, B, first_row=0), g_full)
 
 
 def test_validation_forward_and_predict_mosaic():
