@@ -349,8 +349,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // builtin one before the next LDS read.
 // TMT = rows of the tile (columns: 128).  128: four waves of 64 x 64.  64: four waves of 32 x 64 -- twice the workgroups, for tails
 // that would otherwise leave half of the CUs idle (2,048 rows x 1,024 columns = 128 tiles of 128 x 128, 256 of 64 x 128).
-template <typename T, int EPI, int TMT = 128>
+// X3 (T = float): the three-term f16 split of gemm_nt_kernel_v3<..., X3> on this tile -- activations split in registers, weights
+// pre-split by the host, three `v_mfma_f32_16x16x32_f16` per K tile and accumulator in v3's order (the same bits as v3's rows).
+// Without it an x3 GEMM of 6.125 rounds paid a whole seventh round of the 256 x 256 kernel (0.4 ms at K = 4096).
+template <typename T, int EPI, int TMT = 128, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_tail_kernel(GemmArgs g) {
+  static_assert(!X3 || sizeof(T) == 4, "the three-term f16 split is the float32 kernel's option");
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BK = 8 * EPC;  // elements per 128-byte K tile
   constexpr int NS = 4, ABYTES = TMT * 128, STAGE = ABYTES + 16384;  // [stage][A TMT rows x 128 B | W 128 rows x 128 B]
@@ -412,23 +416,65 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_tail_kernel(GemmArgs g) {
     if (kt + NS - 1 < nk) stage(kt + NS - 1);
     const char* la = smem + (kt & (NS - 1)) * STAGE;
     const char* lw = la + ABYTES;
+    if constexpr (X3) {
+      Chunk fa[2][MI], fw[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Chunk fa[MI], fw[4];
-      const int c = fchunk + 4 * ks;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = fchunk + 4 * ks;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < MI) {
-          const int ra = wr * (TMT / 2) + i * 16 + frow;
-          fa[i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+        for (int i = 0; i < 4; ++i) {
+          if (i < MI) {
+            const int ra = wr * (TMT / 2) + i * 16 + frow;
+            fa[ks][i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+          }
+          const int rw = wc * 64 + i * 16 + frow;
+          fw[ks][i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
         }
-        const int rw = wc * 64 + i * 16 + frow;
-        fw[i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
       }
+      f16x8 ah8[MI], al8[MI];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x = fa[ks][i][e];
+            const f16_t hi = (f16_t)x;
+            ah8[i][4 * ks + e] = hi;
+            al8[i][4 * ks + e] = (f16_t)(x - (float)hi);
+          }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const f16x8 w0 = __builtin_bit_cast(f16x8, fw[0][ni]), w1 = __builtin_bit_cast(f16x8, fw[1][ni]);
+        const f16x8 wh = f16x8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+        const f16x8 wl = f16x8{w0[4], w0[5], w0[6], w0[7], w1[4], w1[5], w1[6], w1[7]};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4& c = acc[ni][mi];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah8[mi], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al8[mi], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah8[mi], c, 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Chunk fa[MI], fw[4];
+        const int c = fchunk + 4 * ks;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < MI) {
+            const int ra = wr * (TMT / 2) + i * 16 + frow;
+            fa[i] = *(const Chunk*)(la + ra * 128 + ((c ^ (ra & 7)) << 4));
+          }
+          const int rw = wc * 64 + i * 16 + frow;
+          fw[i] = *(const Chunk*)(lw + rw * 128 + ((c ^ (rw & 7)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) mma16(acc[ni][mi], fw[ni], fa[mi]);
+      }
     }
   }
   gemm_epilogue<T, EPI, MI>(g, acc, m0 + wr * (TMT / 2), n0 + wc * 64, frow, fchunk);

@@ -169,11 +169,7 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
   // thin (f < 0.3) and the epilogue addresses rows plainly, the rows of that round go to the 128 x 128 kernel
   // instead (2 blocks per CU, 4x more blocks): e.g. M = 100352, N = 1024: 6 full rounds + 128 small tiles.
   constexpr bool kRowPlainEpi = EPI == EPI_PLAIN || EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_FWD || EPI == EPI_BIAS_RESID || EPI == EPI_GELU_BWD;
-  bool no_tail = false;
-  if constexpr (sizeof(T) == 4) {
-    if (g.x3) no_tail = true;  // x3: pre-split weights are readable by the 256 x 256 kernel only -> no 128^2 tail launch
-  }
-  if (!no_tail && kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
+  if (kRowPlainEpi && plain_rows && g.o_rpg == 0 && g.N > 192) {
     const long tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, tiles = tm * tn;
     const long full = tiles / 256, rem = tiles % 256;
     const long tm_main = (full * 256) / tn;  // row tiles that fit in the full rounds
@@ -187,8 +183,22 @@ template <typename T, int AM, int EPI> static void gemm(const bsg_model* m, Gemm
       if (g.out2) b.out2 = (char*)g.out2 + (long)a.M * g.ldo * oes;
       if (g.aux) b.aux = (const char*)g.aux + (long)a.M * g.ldaux * (EPI == EPI_BIAS_RESID ? 4 : sizeof(T));
       a.a_rpg = a.M; b.a_rpg = b.M;
+      if constexpr (sizeof(T) == 4) {  // x3: only the X3 form of the tail kernel reads the pre-split (hi | lo) weights
+        if (g.x3 && (AM != A_PLAIN || g.K / (8 * Traits<T>::EPC) < 3)) { launch_gemm<T, AM, EPI>(g, st); return; }
+      }
       launch_gemm<T, AM, EPI>(a, st);
       const int tiles_b = ((b.M + 127) / 128) * ((b.N + 127) / 128);
+      if constexpr (sizeof(T) == 4 && AM == A_PLAIN) {
+        if (g.x3) {
+          static bool once_x = (allow_lds(gemm_nt_tail_kernel<T, EPI, 128, true>, 131072), allow_lds(gemm_nt_tail_kernel<T, EPI, 64, true>, 98304), true);
+          (void)once_x;
+          if (tiles_b <= 128)
+            hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI, 64, true>), dim3(((b.M + 63) / 64) * ((b.N + 127) / 128), 1), dim3(256), 98304, st, b);
+          else
+            hipLaunchKernelGGL((gemm_nt_tail_kernel<T, EPI, 128, true>), dim3(tiles_b, 1), dim3(256), 131072, st, b);
+          return;
+        }
+      }
       if constexpr (AM == A_PLAIN) {
         if (b.K / (8 * Traits<T>::EPC) >= 3) {  // the four-stage pipeline's prologue requests three K tiles
           static bool once_t = (allow_lds(gemm_nt_tail_kernel<T, EPI, 128>, 131072), allow_lds(gemm_nt_tail_kernel<T, EPI, 64>, 98304), true);

@@ -74,7 +74,8 @@ def test_gemm_fused_epilogues_vs_torch(dtype, M, N, K):
     assert torch.equal(ops.gemm_nt_epilogue("gelu_bwd", a, w, aux=h), d)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256), (25000, 1024, 192)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (777, 1024, 1024), (2 * 1568, 3072, 1024), (4099, 320, 256), (25000, 1024, 192),
+                                   (64 * 1568, 1024, 256)])  # the last: 6.125 rounds -- full rounds on the 256 x 256 kernel + the tail kernel's rows
 def test_gemm_x3_vs_exact(M, N, K):
     """`gemm_nt_kernel_v3<float, ..., X3>`: float32 operands as hi = f16(x), lo = f16(x - hi), three f16 MFMAs per exact-f32
     group (bsg_config.gemm_x3), weights pre-split by the host: against a float64 product -- 22-bit operands leave ~2^-21 of
@@ -90,6 +91,9 @@ def test_gemm_x3_vs_exact(M, N, K):
     print(f"[measured] gemm x3 {M}x{N}x{K}: exact-f32 kernel {e_exact:.1e}, x3 {e_x3:.1e}")
     assert e_x3 < 2e-6 and rel(x3b, ref + b.double()) < 2e-6 and e_exact < 2e-6
     assert torch.isfinite(x3).all()
+    if M == 64 * 1568:  # the tail rows (the last 2,048) on their own: the same accuracy as the rows of the full rounds
+        t0 = M - 2048
+        assert rel(x3[t0:], ref[t0:]) < 2e-6 and rel(exact[t0:], ref[t0:]) < 2e-6 and rel(x3[:t0], ref[:t0]) < 2e-6
 
 
 def _attention_reference(qkv, rel_h, rel_w, dout, S, nh, hp, wp):
