@@ -860,8 +860,8 @@ struct AttnBwdKvArgs {
   int S, nh, N, hp, wp;
   float scale;
   int kr_begin, kr_count;  // attention_kv4.hpp only: the key rows [kr_begin, kr_begin + kr_count) this launch covers
-  // attention_kv4.hpp only (the other kernels compute everything, a superset): queries < q_begin (a multiple of 64) contribute
-  // exact zeros and are not streamed; only the first key_rows key rows are wanted (0 = all Hp), the others are NOT written
+  // row windows (bsg_backward_rows): queries < q_begin (a multiple of 64) contribute exact zeros and are not streamed; only the
+  // first key_rows key rows are wanted (0 = all Hp) -- rows past them (rounded up to a launch's row group) are NOT written
   int q_begin, key_rows;
 };
 
@@ -908,8 +908,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs 
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, col = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bx, head, s;
-  attn_block_ids((a.hp + NW - 1) / NW, a.nh, a.S, bx, head, s);
-  const int nt = (a.N + QT - 1) / QT;
+  const int key_rows = a.key_rows > 0 && a.key_rows < a.hp ? a.key_rows : a.hp;  // the launcher's grid covers these rows (rounded up to NW)
+  attn_block_ids((key_rows + NW - 1) / NW, a.nh, a.S, bx, head, s);
+  const int nt = (a.N + QT - 1) / QT, t0 = a.q_begin / QT;  // queries below q_begin contribute exact zeros (their dO rows are zero)
   const int kr0 = bx * NW;
   const bool wave_valid = kr0 + wave < a.hp;
   const int kr = min(kr0 + wave, a.hp - 1);  // this wave's key grid row (clamped duplicates do not store)
@@ -978,8 +979,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(AttnBwdKvArgs 
     });
   };
 
-  issue(0, 0);
-  for (int t = 0; t < nt; ++t) {
+  issue(t0, t0 & 1);
+  for (int t = t0; t < nt; ++t) {
     const int buf = t & 1;
     wait_vm0();
     __syncthreads();

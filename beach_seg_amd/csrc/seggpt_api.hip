@@ -283,7 +283,8 @@ template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t
       return;
     }
   }
-  const dim3 kgrid(((k.hp + 7) / 8) * k.nh * k.S);
+  const int krows = k.key_rows > 0 && k.key_rows < k.hp ? k.key_rows : k.hp;  // row windows: see AttnBwdKvArgs
+  const dim3 kgrid(((krows + 7) / 8) * k.nh * k.S);
   if constexpr (!tr) {
     if (x3) {  // exact-f32 storage, three f16 MFMAs per f32 MFMA quadruple (attention.hpp mma32_x3)
       constexpr int lds3 = 2 * DkvK<T, false, 64>::STAGE;
@@ -298,7 +299,7 @@ template <typename T> static void launch_dkv(const AttnBwdKvArgs& k, hipStream_t
       constexpr int lds = 2 * DkvK<T, true, 64>::STAGE;
       static bool once4 = (allow_lds(attn_bwd_dkv_kernel<T, true, 64, false, 4>, lds), true);
       (void)once4;
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, 64, false, 4>), dim3((k.hp / 4) * k.nh * k.S), dim3(256), lds, st, k);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, 64, false, 4>), dim3(((krows + 3) / 4) * k.nh * k.S), dim3(256), lds, st, k);
       return;
     }
     if (((k.N + 127) & ~127) <= k.hp * 32) {
@@ -688,7 +689,6 @@ template <typename T> static int backward_impl(bsg_model* m, hipStream_t st, int
       k.q_begin = top_block ? zero_tokens / 64 * 64 : 0;
       k.key_rows = l == 0 ? (hp + 1) / 2 : 0;
       {
-        // (credited as if the windows applied; the kernels that ignore them -- f32, token grids the four-wave form does not take -- do more)
         ProfScope ps(m, st, PC_ATTN_BWD_DKV, 4.0 * B * nh * (double)N * N * 64 * ((double)(N - k.q_begin) / N) * (k.key_rows ? (double)k.key_rows / hp : 1.0));
         launch_dkv<T>(k, st, m->c.gemm_x3 != 0);
       }
@@ -1094,12 +1094,12 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     launch_dkv<T>(k, st);
     CHECK_LAUNCH();
   }
-  g_attn_win[0] = g_attn_win[1] = g_attn_win[2] = g_attn_win[3] = 0;
   if (which & 16) {  // A/B: the eight-wave dK / dV kernel (one workgroup per CU)
     AttnBwdKvArgs k{};
     k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
     k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
     k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    k.q_begin = g_attn_win[2]; k.key_rows = g_attn_win[3];
     launch_dkv<T>(k, st, false, 1);
     CHECK_LAUNCH();
   }
@@ -1108,6 +1108,7 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     k.k = q + D; k.v = q + 2 * D; k.q = q; k.dout = dout; k.ld = 3 * D; k.ldo = D; k.relwT = relwT; k.relhT = relhT;
     k.lse2 = lse2; k.delta = delta; k.dk = (T*)dqkv + D; k.dv = (T*)dqkv + 2 * D;
     k.S = S; k.nh = nh; k.N = N; k.hp = hp; k.wp = wp; k.scale = 0.125f;
+    k.q_begin = g_attn_win[2]; k.key_rows = g_attn_win[3];
     launch_dkv<T>(k, st, false, 2);
     CHECK_LAUNCH();
   }
@@ -1119,6 +1120,7 @@ static int op_attention_impl(void* stream, int which, int S, int nh, int hp, int
     launch_dkv4<T>(k, st);
     CHECK_LAUNCH();
   }
+  g_attn_win[0] = g_attn_win[1] = g_attn_win[2] = g_attn_win[3] = 0;
   return 0;
 }
 

@@ -260,11 +260,11 @@ int bsg_op_attention(void* stream, int dtype, int which, int S, int nh, int hp, 
                      const void* rel_catT, const void* dout, void* out, float* lse2, void* dqkv, void* scratch,
                      size_t scratch_bytes);
 
-/* Row windows for the dQ (bit 1) and default dK/dV (bit 2) kernels of the NEXT bsg_op_attention call of this thread, as
+/* Row windows for the dQ (bit 1) and dK/dV (bits 2, 4, 5) kernels of the NEXT bsg_op_attention call of this thread, as
  * bsg_backward_rows applies them (unit tests): dq is wanted for the queries [dq_begin, dq_end) only (dq_end = 0: to N; rows of
  * 128-query workgroups wholly outside come back zero); dK/dV streams the queries >= q_begin (a multiple of 64: the caller
- * guarantees dout == 0 below) and, where the one-wave-per-SIMD kernel runs, writes only the first key_rows key rows (0 = all).
- * The windows are consumed by that call. */
+ * guarantees dout == 0 below) and writes only the first key_rows key rows (0 = all), rounded up to the kernel's row group
+ * (exact for the one-wave-per-SIMD kernel, 8 / 4 rows for bits 4 / 5).  The windows are consumed by that call. */
 int bsg_op_attention_windows(int dq_begin, int dq_end, int q_begin, int key_rows);
 
 /* Optional per-launch timing (HIP events recorded on the caller's stream around the kernels of one category):

@@ -200,3 +200,16 @@ def test_attention_backward_row_windows_are_exact(hp, wp, S, nh, dtype):
     assert torch.equal(w3[:, :key_rows * wp, D:], f3[:, :key_rows * wp, D:])
     assert bool((w3[:, key_rows * wp:, D:] == 7.0).all())  # not written
     assert torch.isfinite(win.float()).all()
+    # the eight-wave kernel (what the f32 / x3 modes and other token grids run; bit 4) and the 2 x 4-wave form (bit 5) take the same
+    # windows; their key window is rounded up to the row group of a workgroup
+    for bit, grp in ((16, 8), (32, 4)):
+        rows = (key_rows + grp - 1) // grp * grp * wp
+        full_v, win_v = torch.zeros_like(qkv), torch.full_like(qkv, 7.0)
+        run(2 | bit, dout, full_v)
+        run(2 | bit, dout, win_v, (0, q_end, 0, key_rows))
+        fv, wv = full_v.reshape(S, N, 3 * D), win_v.reshape(S, N, 3 * D)
+        assert torch.equal(wv[:, :rows, D:], fv[:, :rows, D:]) and bool((wv[:, rows:, D:] == 7.0).all()), bit
+        full_v, win_v = torch.zeros_like(qkv), torch.full_like(qkv, 7.0)
+        run(2 | bit, dz, full_v)
+        run(2 | bit, dz, win_v, (zero_tok // 128 * 128, 0, zero_tok // 64 * 64, 0))
+        assert torch.equal(win_v, full_v), bit
